@@ -1,0 +1,61 @@
+// msnake_internal.h -- shared between the kernels and the C-ABI glue (not installed).
+#ifndef MSNAKE_INTERNAL_H
+#define MSNAKE_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/msnake.h"
+
+// One wavefront per env; up to 4 envs (256 threads) per workgroup, no workgroup barrier anywhere.
+#define MSNAKE_BLOCK_THREADS 256
+#define MSNAKE_MAX_ENVS_PER_BLOCK 4
+
+// Per-env header record in HBM: 64 dwords = 256 B, loaded/stored by ONE coalesced wave
+// instruction (lane l <-> word l).  Everything the sequential game logic needs is in here, so a
+// step makes exactly one dependent round trip (header -> body chunk) before it can decide.
+#define MSNAKE_HDR_WORDS 64
+#define HDR_T 0          // steps since reset ([S] state[4] / [NE] current_step)
+#define HDR_CTR_LO 1     // Philox draws consumed (64 bit)
+#define HDR_CTR_HI 2
+#define HDR_EP_RETURN 3  // Monitor: running episode return (f32 bits)
+#define HDR_EP_LEN 4     // Monitor: running episode length
+#define HDR_SPARE 5      // [A] spare_fruits
+#define HDR_NLIST 6      // [A] length of the fruit list
+#define HDR_FLAGS 7      // [N] bit s: Snake.alive, bit 4+s: snake in World.dead_snakes
+#define HDR_SNAKE0 8     // 4 words per snake: {ring head pos | len<<16, grow_to, head cell | vel<<16, -}
+#define HDR_FRUIT0 32    // word 32+f: fruit f's cell (snake_env / new_world keep fruits inline)
+
+#define MSNAKE_NO_CELL 0xFFFFu  // never equals a real cell (rows/cols <= 63)
+
+namespace msnake {
+
+struct StepParams {
+    // configuration
+    int32_t nenv, dim, n_snakes, n_fruits, views, C, S, max_steps, auto_reset;
+    int32_t cap;           // ring capacity in cells (multiple of 64)
+    int32_t lds_per_wave;  // bytes of LDS per env: image chunks + occupancy bytes
+    int32_t occ_off, occ_bytes;
+    int32_t tmpl_stride;   // bytes between the 16 byte-shifted background images
+    int32_t action_stride;
+    uint32_t seed_lo, seed_hi;
+    uint64_t env_id_base;
+    // state (HBM, owned by the handle)
+    uint32_t* hdr;               // [nenv][64]
+    uint16_t* ring;              // [nenv][n_snakes][cap] body cells, piece i at (head_pos + i) % cap
+    const uint8_t* tmpl;         // [16][tmpl_stride]
+    unsigned long long* stats;   // [8]
+    // per-call i/o (device pointers owned by the caller)
+    const int32_t* actions;
+    uint8_t* obs;
+    float* rew;
+    uint8_t* done;
+    msnake_info* info;
+};
+
+hipError_t launch_step(const StepParams& p, int rules, int mode, int envs_per_block, hipStream_t stream);
+const char* step_kernel_name(int rules);
+
+}  // namespace msnake
+
+#endif

@@ -1,0 +1,211 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the golden fixtures
+recorded from the reference and against the CPU oracle on the same seeded inputs.  Bit-exact:
+this is integer / byte work, there is no tolerance anywhere."""
+import numpy as np
+import pytest
+
+from golden_util import blob_to_obs, crc_rows, edge_cases, load_tape, state_view, tape_names, unpack_state
+
+pytestmark = pytest.mark.gpu
+
+SUPPORTED_RULES = (0, 1)
+
+
+def _mk(**kw):
+    import msnake
+    return msnake.MultiSnakeVecEnv(**kw)
+
+
+def _state(env, e):
+    from oracle.snake_oracle import flat_to_state
+    return flat_to_state(env.get_state_words(e))
+
+
+def _set_state(env, e, st):
+    from oracle.snake_oracle import state_to_flat
+    env.set_state_words(e, state_to_flat(st, env.n_snakes))
+
+
+@pytest.mark.parametrize("case", [c for c in edge_cases() if c["rules"] in SUPPORTED_RULES], ids=lambda c: c["name"])
+def test_edge_case(case):
+    rules = case["rules"]
+    env = _mk(num_envs=1, dim=case["dim"], n_snakes=case["n_snakes"], n_fruits=case["n_fruits"], rules=rules,
+              seed=case["seed"], env_id_base=case["env_id"], auto_reset=False)
+    env.reset()
+    _set_state(env, 0, case["state0"])
+    assert state_view(_state(env, 0), rules) == state_view(case["state0"], rules)
+    assert np.array_equal(env.render()[0], blob_to_obs(case["obs0"]))
+    for i, step in enumerate(case["steps"]):
+        if step["actions"] == "reset":
+            obs = env.reset()
+        else:
+            obs, rew, done, infos = env.step(np.array([step["actions"]], np.int32))
+            assert float(rew[0]) == step["reward"], (case["name"], i)
+            assert bool(done[0]) == step["done"], (case["name"], i)
+            assert infos[0]["num_snakes"] == step["num_snakes"], (case["name"], i)
+        assert state_view(_state(env, 0), rules) == state_view(step["state"], rules), (case["name"], i)
+        assert np.array_equal(obs[0], blob_to_obs(step["obs"])), (case["name"], i)
+    assert env.stats()["errors"] == 0
+    env.close()
+
+
+@pytest.mark.parametrize("name", [n for n in tape_names() if load_tape(n)[0]["rules"] in SUPPORTED_RULES])
+def test_golden_tape(name):
+    meta, z = load_tape(name)
+    rules, E, T = meta["rules"], meta["num_envs"], meta["steps"]
+    env = _mk(num_envs=E, dim=meta["dim"], n_snakes=meta["n_snakes"], n_fruits=meta["n_fruits"], rules=rules,
+              seed=meta["seed"], env_id_base=meta["env_id_base"], max_steps=meta["max_steps"],
+              auto_reset=meta["auto_reset"])
+    assert np.array_equal(env.reset(), z["obs0"])
+    for e in range(E):
+        assert state_view(_state(env, e), rules) == unpack_state(z, "s0_", 0, e, rules)
+    full_t = {int(t): i for i, t in enumerate(z["full_obs_t"])}
+    actions = z["actions"].astype(np.int32)
+    for t in range(T):
+        obs, rew, done, infos = env.step(actions[t])
+        assert np.array_equal(rew, z["reward"][t]), (name, t)
+        assert np.array_equal(done, z["done"][t].astype(bool)), (name, t)
+        assert np.array_equal(infos._ns, z["num_snakes"][t].astype(np.int32)), (name, t)
+        assert np.array_equal(infos._r, z["ep_return"][t]), (name, t)
+        assert np.array_equal(infos._l, z["ep_len"][t]), (name, t)
+        assert np.array_equal(crc_rows(obs), z["obs_crc"][t]), (name, t)
+        if t in full_t:
+            assert np.array_equal(obs, z["full_obs"][full_t[t]]), (name, t)
+        if t % 16 == 0 or t == T - 1:
+            for e in range(0, E, 3):
+                assert state_view(_state(env, e), rules) == unpack_state(z, "st_", t, e, rules), (name, t, e)
+    assert env.stats()["errors"] == 0
+    env.close()
+
+
+def _run_vs_oracle(num_envs, dim, n_snakes, n_fruits, rules, steps, seed, env_id_base=0, greedy=0.0):
+    """Same seeded action stream into the HIP env and the oracle; everything must match."""
+    from oracle.snake_oracle import Oracle
+    env = _mk(num_envs=num_envs, dim=dim, n_snakes=n_snakes, n_fruits=n_fruits, rules=rules, seed=seed,
+              env_id_base=env_id_base)
+    ora = Oracle(num_envs, dim=dim, n_snakes=n_snakes, n_fruits=n_fruits, rules=rules, seed=seed,
+                 env_id_base=env_id_base)
+    assert np.array_equal(env.reset(), ora.reset())
+    rs = np.random.default_rng(seed + 17)
+    n_done = 0
+    for t in range(steps):
+        act = rs.integers(0, 5, (num_envs, n_snakes)).astype(np.int32)
+        if greedy:  # bias towards "keep going" so snakes live longer and grow
+            keep = rs.random((num_envs, n_snakes)) < greedy
+            act = np.where(keep, 0, act).astype(np.int32)
+        obs, rew, done, infos = env.step(act)
+        o_obs, o_rew, o_done, o_ns, o_er, o_el = ora.step(act, threads=8)
+        assert np.array_equal(rew, o_rew), t
+        assert np.array_equal(done, o_done.astype(bool)), t
+        assert np.array_equal(infos._ns, o_ns), t
+        assert np.array_equal(infos._r, o_er), t
+        assert np.array_equal(infos._l, o_el), t
+        assert np.array_equal(obs, o_obs), t
+        n_done += int(done.sum())
+    st = env.stats()
+    assert st["errors"] == 0
+    assert st["episodes"] == n_done and st["env_steps"] == steps * num_envs
+    for e in range(0, num_envs, max(1, num_envs // 64)):
+        got, want = _state(env, e), ora.get_state(e)
+        assert got == want, e
+    env.close()
+    return n_done
+
+
+def test_config2_4096_envs_10x10_1snake():
+    assert _run_vs_oracle(4096, 10, 1, 1, "snake_env", 200, seed=0) > 1000
+
+
+def test_config3_4096_envs_19x19_3snakes():
+    assert _run_vs_oracle(4096, 19, 3, 3, "snake_env", 200, seed=0) > 1000
+
+
+def test_config5_shape_19x19_2snakes_long_lived():
+    _run_vs_oracle(2048, 19, 2, 2, "snake_env", 300, seed=4, greedy=0.7)
+
+
+def test_new_world_4096_envs():
+    _run_vs_oracle(4096, 19, 3, 3, "new_world", 100, seed=2)
+    _run_vs_oracle(1024, 10, 2, 4, "new_world", 100, seed=3)
+    _run_vs_oracle(256, 10, 4, 4, "new_world", 100, seed=3)
+
+
+@pytest.mark.parametrize("num_envs", [1, 2, 5, 17, 63, 130])
+def test_ragged_batch_sizes_and_unaligned_images(num_envs):
+    """3969-byte images are not 16-byte multiples: every misalignment 0..15 of the per-env image
+    and the byte-store edges are exercised; guard bytes around the tensor must stay untouched."""
+    import torch
+    from oracle.snake_oracle import Oracle
+    env = _mk(num_envs=num_envs, dim=19, n_snakes=3, rules="snake_env", seed=9)
+    ora = Oracle(num_envs, dim=19, n_snakes=3, rules="snake_env", seed=9)
+    H, W, C = env.obs_shape
+    nbytes = num_envs * H * W * C
+    for lead in (0, 3, 16):
+        buf = torch.full((nbytes + 64,), 0xAB, dtype=torch.uint8, device=env.device)
+        out = buf[lead:lead + nbytes].view(num_envs, H, W, C)
+        got = env.reset_device(out=out).cpu().numpy()
+        assert np.array_equal(got, ora.reset())
+        act = np.random.default_rng(lead).integers(0, 5, (num_envs, 3)).astype(np.int32)
+        obs, _, _, _ = env.step_device(torch.from_numpy(act).to(env.device), out=out)
+        assert np.array_equal(obs.cpu().numpy(), ora.step(act)[0])
+        host = buf.cpu().numpy()
+        assert (host[:lead] == 0xAB).all() and (host[lead + nbytes:] == 0xAB).all()
+    env.close()
+
+
+def test_sharding_is_invisible():
+    """Two handles owning global envs [0,1024) and [1024,2048) == one handle owning [0,2048)."""
+    whole = _mk(num_envs=2048, dim=19, n_snakes=3, rules="snake_env", seed=5)
+    lo = _mk(num_envs=1024, dim=19, n_snakes=3, rules="snake_env", seed=5, env_id_base=0)
+    hi = _mk(num_envs=1024, dim=19, n_snakes=3, rules="snake_env", seed=5, env_id_base=1024)
+    assert np.array_equal(whole.reset(), np.concatenate([lo.reset(), hi.reset()]))
+    rs = np.random.default_rng(1)
+    for _ in range(60):
+        act = rs.integers(0, 5, (2048, 3)).astype(np.int32)
+        a = whole.step(act)
+        b, c = lo.step(act[:1024]), hi.step(act[1024:])
+        for k in range(3):
+            assert np.array_equal(a[k], np.concatenate([b[k], c[k]]))
+    for env in (whole, lo, hi):
+        env.close()
+
+
+def test_step_tape_equals_single_steps():
+    import ctypes
+    import torch
+    import msnake
+    n, T = 512, 16
+    a = _mk(num_envs=n, dim=19, n_snakes=3, rules="snake_env", seed=8)
+    b = _mk(num_envs=n, dim=19, n_snakes=3, rules="snake_env", seed=8)
+    a.reset(); b.reset()
+    tape = torch.randint(0, 5, (T, n, 3), dtype=torch.int32, device=a.device)
+    H, W, C = a.obs_shape
+    obs = torch.empty((T, n, H, W, C), dtype=torch.uint8, device=a.device)
+    rew = torch.empty((T, n), dtype=torch.float32, device=a.device)
+    done = torch.empty((T, n), dtype=torch.uint8, device=a.device)
+    info = torch.empty((T, n, 4), dtype=torch.int32, device=a.device)
+    msnake._capi.check(a._L.msnake_step_tape(a._h, tape.data_ptr(), 3, T, obs.data_ptr(), n * H * W * C,
+                                             rew.data_ptr(), done.data_ptr(), info.data_ptr(), n, a._stream()))
+    for t in range(T):
+        o, r, d, i = b.step_device(tape[t])
+        assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(d, done[t]) and torch.equal(i, info[t])
+    a.close(); b.close()
+
+
+def test_errors_are_exceptions():
+    import torch
+    with pytest.raises(RuntimeError, match="n_snakes"):
+        _mk(num_envs=4, dim=19, n_snakes=5, rules="snake_env")
+    with pytest.raises(RuntimeError, match="dim"):
+        _mk(num_envs=4, dim=200, n_snakes=3, rules="snake_env")
+    env = _mk(num_envs=4, dim=10, n_snakes=2, rules="snake_env")
+    env.reset()
+    with pytest.raises(ValueError):
+        env.step(np.zeros((4, 1), np.int32))
+    with pytest.raises(ValueError):
+        env.step(np.zeros((3, 2), np.int32))
+    with pytest.raises(RuntimeError, match="snakes"):
+        env.set_state_words(0, np.zeros(8, np.int32))
+    env.close()
+    with pytest.raises(RuntimeError, match="handle"):
+        env.step_device(torch.zeros((4, 2), dtype=torch.int32, device="cuda"))
