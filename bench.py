@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the HIP batched multi-snake step (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE lockstep step of every env of the batch = one msnake_step kernel launch through
+the C-ABI (include/msnake.h), actions already resident in HBM, observations / rewards / dones /
+info written to HBM.  Workload at every N: 4 096 envs per GPU, 19x19 grid, 3 snakes, snake_env
+rules, auto-reset on (BASELINE.json configs[2]; configs[3] = the same per-GPU shard on 8 GPUs), so
+scaling is weak.  Envs never communicate: ranks shard the global env ids with no data-path
+collective; RCCL is used once, after the timed region, to all-gather the episode statistics.
+
+Prints ONE JSON line (rank 0).  Extra keys beside the driver's contract:
+  roofline     : dominant kernel vs the HBM roofline (algorithmic bytes per launch from
+                 msnake_algorithmic_bytes_per_env_step() x envs, duration from HIP events on the
+                 launch stream over the timed region; PMC traffic from profiles/ when present)
+  cpu_baseline : the CPU oracle (oracle/snake_oracle.c, the parity-pinned port of the reference)
+                 timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+DIM, N_SNAKES = 19, 3
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(actions_host, seconds=12.0):
+    """Oracle on all host cores, same action tape, bounded to ~`seconds` of wall time."""
+    from oracle import snake_oracle
+    n = actions_host.shape[1]
+    cores = max(1, min(snake_oracle.lib().orc_max_threads(), len(os.sched_getaffinity(0))))
+    ora = snake_oracle.Oracle(n, dim=DIM, n_snakes=N_SNAKES, rules="snake_env", seed=0)
+    ora.reset()
+    ora.step(actions_host[0], threads=cores)  # warm
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        ora.step(actions_host[k % len(actions_host)], threads=cores)
+        k += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or k >= 4096:
+            break
+    return {"value": round(n * k / el, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{k} lockstep steps of {n} envs (19x19, 3 snakes, obs render included) in {el:.1f}s, "
+                      f"OpenMP over env ranges"}
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch from the committed PMC pass (profiles/hbm_traffic_r01.json), or None."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic_r01.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--python-loop", action="store_true", help="issue launches from Python instead of msnake_step_tape")
+    args = ap.parse_args()
+
+    import torch
+    import msnake
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    if args.gpus != world:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n = args.envs_per_gpu
+    K, Wm = args.steps, args.warmup
+
+    env = msnake.MultiSnakeVecEnv(n, dim=DIM, n_snakes=N_SNAKES, rules="snake_env", seed=0,
+                                  env_id_base=rank * n, device=dev)
+    # synthetic input: uniform random actions in [0,5), one tape shared by the GPU and CPU runs
+    T = 256
+    tape_h = np.random.default_rng(1234 + rank).integers(0, 5, (T, n, N_SNAKES)).astype(np.int32)
+    tape = torch.from_numpy(tape_h).to(dev)
+    env.reset_device()
+    H, Wd, C = env.obs_shape
+    L, h = env._L, env._h
+    obs, rew, done, info = env._obs, env._rew, env._done, env._info
+
+    def run(nsteps, start):
+        """nsteps launches; the tape wraps every T steps."""
+        k = 0
+        while k < nsteps:
+            off = (start + k) % T
+            m = min(nsteps - k, T - off)
+            if args.python_loop:
+                for j in range(m):
+                    env.step_device(tape[off + j])
+            else:
+                msnake._capi.check(L.msnake_step_tape(h, tape[off].data_ptr(), N_SNAKES, m, obs.data_ptr(), 0,
+                                                      rew.data_ptr(), done.data_ptr(), info.data_ptr(), 0,
+                                                      env._stream()), "msnake_step_tape")
+            k += m
+
+    run(Wm, 0)
+    torch.cuda.synchronize()
+    env.stats(reset=True)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(K, Wm)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+
+    st = env.stats()
+    assert st["errors"] == 0 and st["env_steps"] == K * n, st
+    # the only collective of the path: all-gather of the per-rank episode statistics (RCCL)
+    rec = torch.tensor([st["episodes"], st["ep_len_sum"], st["ep_return_sum"], st["env_steps"]],
+                       dtype=torch.int64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist:
+        allrec = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(allrec, rec)
+        rec = torch.stack(allrec).sum(0)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    episodes, len_sum, ret_sum, steps_total = (int(x) for x in rec.tolist())
+
+    if rank == 0:
+        value = steps_total / elapsed
+        bytes_per_env_step = env.algorithmic_bytes_per_env_step()
+        bytes_per_launch = bytes_per_env_step * n
+        launch_us = dev_ms * 1e3 / K
+        achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
+        out = {
+            "metric": "env-steps/sec (agent·step) at 4 096×19×19×3-snake, 1/2/4/8 GPU + CPU ref",
+            "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(elapsed * 1e3 / K, 6), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{n} envs/GPU x {DIM}x{DIM} x {N_SNAKES} snakes, snake_env rules, auto-reset, "
+                                   f"native {H}x{Wd}x{C} uint8 obs, uniform random actions (BASELINE configs[2]"
+                                   + ("/[3]" if world > 1 else "") + ")",
+                       "envs_total": n * world, "agent_steps_per_s": round(value * N_SNAKES, 1),
+                       "launch": "python per-step" if args.python_loop else "msnake_step_tape (C loop, 1 launch/step)",
+                       "mean_episode_len": round(len_sum / max(1, episodes), 2),
+                       "mean_episode_return": round(ret_sum / max(1, episodes), 3)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(),
+                         "kernel": env.kernel_name(), "launch_us": round(launch_us, 3),
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(tape_h)
+        print(json.dumps(out), flush=True)
+    env.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

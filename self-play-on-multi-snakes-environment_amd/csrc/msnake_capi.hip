@@ -55,6 +55,7 @@ struct msnake_env {
     hipStream_t last_stream;
     int64_t env_steps;
     void* d_hdr;
+    void* d_body0;
     void* d_ring;
     void* d_tmpl;
     void* d_stats;
@@ -154,13 +155,15 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
 
     const size_t hdr_bytes = (size_t)p.nenv * MSNAKE_HDR_WORDS * 4;
     const size_t ring_bytes = (size_t)p.nenv * p.n_snakes * p.cap * 2;
+    const size_t body0_bytes = (size_t)p.nenv * p.n_snakes * 64 * 2;
     const size_t tmpl_bytes = (size_t)16 * p.tmpl_stride;
     hipError_t e;
     if ((e = hipMalloc(&h->d_hdr, hdr_bytes)) != hipSuccess || (e = hipMalloc(&h->d_ring, ring_bytes)) != hipSuccess ||
+        (e = hipMalloc(&h->d_body0, body0_bytes)) != hipSuccess || (e = hipMemset(h->d_body0, 0, body0_bytes)) != hipSuccess ||
         (e = hipMalloc(&h->d_tmpl, tmpl_bytes)) != hipSuccess || (e = hipMalloc(&h->d_stats, 64)) != hipSuccess ||
         (e = hipMemset(h->d_hdr, 0, hdr_bytes)) != hipSuccess || (e = hipMemset(h->d_ring, 0, ring_bytes)) != hipSuccess ||
         (e = hipMemset(h->d_stats, 0, 64)) != hipSuccess) {
-        (void)hipFree(h->d_hdr); (void)hipFree(h->d_ring); (void)hipFree(h->d_tmpl); (void)hipFree(h->d_stats);
+        (void)hipFree(h->d_hdr); (void)hipFree(h->d_body0); (void)hipFree(h->d_ring); (void)hipFree(h->d_tmpl); (void)hipFree(h->d_stats);
         free(h);
         return fail(MSNAKE_E_HIP, "allocating %zu bytes of env state failed: %s", hdr_bytes + ring_bytes + tmpl_bytes,
                     hipGetErrorString(e));
@@ -174,12 +177,13 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
                 if (r == 0 || r == W - 1 || c == 0 || c == W - 1)
                     memset(&tmpl[(size_t)a * p.tmpl_stride + a + ((size_t)r * W + c) * p.C], 255, (size_t)p.C);
     if ((e = hipMemcpy(h->d_tmpl, tmpl.data(), tmpl_bytes, hipMemcpyHostToDevice)) != hipSuccess) {
-        (void)hipFree(h->d_hdr); (void)hipFree(h->d_ring); (void)hipFree(h->d_tmpl); (void)hipFree(h->d_stats);
+        (void)hipFree(h->d_hdr); (void)hipFree(h->d_body0); (void)hipFree(h->d_ring); (void)hipFree(h->d_tmpl); (void)hipFree(h->d_stats);
         free(h);
         return fail(MSNAKE_E_HIP, "uploading the background image failed: %s", hipGetErrorString(e));
     }
     p.hdr = static_cast<uint32_t*>(h->d_hdr);
     p.ring = static_cast<uint16_t*>(h->d_ring);
+    p.body0 = static_cast<uint16_t*>(h->d_body0);
     p.tmpl = static_cast<const uint8_t*>(h->d_tmpl);
     p.stats = static_cast<unsigned long long*>(h->d_stats);
     h->magic = kMagic;
@@ -191,7 +195,7 @@ int msnake_destroy(msnake_handle h) {
     if (int rc = check(h)) return rc;
     DeviceGuard guard(h->cfg.device);
     (void)hipDeviceSynchronize();
-    (void)hipFree(h->d_hdr); (void)hipFree(h->d_ring); (void)hipFree(h->d_tmpl); (void)hipFree(h->d_stats);
+    (void)hipFree(h->d_hdr); (void)hipFree(h->d_body0); (void)hipFree(h->d_ring); (void)hipFree(h->d_tmpl); (void)hipFree(h->d_stats);
     h->magic = 0;
     free(h);
     return MSNAKE_OK;
@@ -313,6 +317,7 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
     if (words[6] != p.n_fruits) return fail(MSNAKE_E_STATE, "state has %d fruits, handle has %d", words[6], p.n_fruits);
     uint32_t hdr[MSNAKE_HDR_WORDS] = {0};
     std::vector<uint16_t> ring((size_t)p.n_snakes * p.cap, 0);
+    std::vector<uint16_t> body0((size_t)p.n_snakes * 64, 0);
     auto cell = [&](int32_t c0, int32_t c1, uint32_t* out) -> bool {
         if (c0 < -1 || c0 > p.dim || c1 < -1 || c1 > p.dim) return false;
         *out = ((uint32_t)(c0 + 1) << 8) | (uint32_t)(c1 + 1);
@@ -341,6 +346,7 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
             uint32_t c;
             if (!cell(words[k], words[k + 1], &c)) return fail(MSNAKE_E_STATE, "snake %d piece %d outside [-1, dim]", s, i);
             ring[(size_t)s * p.cap + i] = (uint16_t)c;
+            if (i < 64) body0[(size_t)s * 64 + i] = (uint16_t)c;
             if (i == 0) headc = c;
         }
         hdr[HDR_SNAKE0 + 4 * s] = 0u | ((uint32_t)len << 16);
@@ -354,6 +360,7 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(p.hdr + (size_t)env * MSNAKE_HDR_WORDS, hdr, sizeof(hdr), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p.ring + (size_t)env * p.n_snakes * p.cap, ring.data(), ring.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p.body0 + (size_t)env * p.n_snakes * 64, body0.data(), body0.size() * 2, hipMemcpyHostToDevice));
     return MSNAKE_OK;
 }
 
@@ -379,7 +386,7 @@ int msnake_get_stats(msnake_handle h, msnake_stats* out, int32_t reset) {
 
 const char* msnake_kernel_name(msnake_handle h) {
     if (check(h)) return "";
-    return msnake::step_kernel_name(h->cfg.rules);
+    return msnake::step_kernel_name(h->cfg.rules, h->cfg.n_snakes);
 }
 
 int64_t msnake_algorithmic_bytes_per_env_step(msnake_handle h) {

@@ -11,9 +11,9 @@
 #define MSNAKE_BLOCK_THREADS 256
 #define MSNAKE_MAX_ENVS_PER_BLOCK 4
 
-// Per-env header record in HBM: 64 dwords = 256 B, loaded/stored by ONE coalesced wave
-// instruction (lane l <-> word l).  Everything the sequential game logic needs is in here, so a
-// step makes exactly one dependent round trip (header -> body chunk) before it can decide.
+// Per-env record in HBM: 64 dwords = 256 B, loaded/stored by ONE coalesced wave instruction
+// (lane l <-> word l), plus 128 B per snake with its first 64 body cells in logical order.  Both
+// sit at addresses that depend only on the env index: one memory round trip per step.
 #define MSNAKE_HDR_WORDS 64
 #define HDR_T 0          // steps since reset ([S] state[4] / [NE] current_step)
 #define HDR_CTR_LO 1     // Philox draws consumed (64 bit)
@@ -42,7 +42,8 @@ struct StepParams {
     uint64_t env_id_base;
     // state (HBM, owned by the handle)
     uint32_t* hdr;               // [nenv][64]
-    uint16_t* ring;              // [nenv][n_snakes][cap] body cells, piece i at (head_pos + i) % cap
+    uint16_t* body0;             // [nenv][n_snakes][64] the first 64 body cells in logical order
+    uint16_t* ring;              // [nenv][n_snakes][cap] every body cell, piece i at (head_pos + i) % cap
     const uint8_t* tmpl;         // [16][tmpl_stride]
     unsigned long long* stats;   // [8]
     // per-call i/o (device pointers owned by the caller)
@@ -54,7 +55,7 @@ struct StepParams {
 };
 
 hipError_t launch_step(const StepParams& p, int rules, int mode, int envs_per_block, hipStream_t stream);
-const char* step_kernel_name(int rules);
+const char* step_kernel_name(int rules, int n_snakes);
 
 }  // namespace msnake
 

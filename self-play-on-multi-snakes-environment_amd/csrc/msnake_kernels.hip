@@ -1,18 +1,22 @@
 // msnake_kernels.hip -- the batched multi-snake environment step for gfx950 (MI355X, CDNA4).
 //
 // One 64-lane wavefront owns one environment for the whole step; a 256-thread workgroup carries
-// four independent envs and never executes a workgroup barrier.  Game logic runs on wave-uniform
-// (scalar) values; the lanes cooperate on the O(body) and O(dim^2) jobs:
-//   * body pieces are lane-distributed (lane l = piece l): collisions are 64 compares + a ballot
-//     (head-vs-piece matrix), fruit eating is a ballot over lane-resident fruits;
-//   * fruit respawn = occupancy bytes in LDS -> per-chunk ballots parked in lanes -> k-th free cell
-//     by popcount / mbcnt (no loop over cells);
+// four independent envs and never executes a workgroup barrier.  Design points:
+//   * ONE memory round trip before the wave can decide: the 256-byte env record (lane l <-> word
+//     l), the first 64 body cells of every snake (lane l <-> piece l) and the actions are all at
+//     addresses that depend only on the env index, so they are issued together at kernel entry.
+//     Only bodies longer than 64 cells touch the full ring (dependent loads, rare).
+//   * the env record stays in ONE VGPR for the whole kernel: scalar game logic reads fields with
+//     v_readlane and writes them back by lane select, so almost nothing is live in SGPRs;
+//   * body pieces are lane-distributed: a move is a one-lane shift of the chunk, collisions are
+//     compares + ballots (head-vs-piece matrix), fruit eating is a ballot over lane-resident fruits;
+//   * fruit respawn (slow path, once in the code): occupancy bytes in LDS -> per-chunk ballots
+//     parked in lanes -> k-th free cell by popcount / mbcnt; Philox4x32-10 on the scalar unit;
 //   * the observation is composed in LDS: a precomputed wall/background image (L2-resident,
-//     16 byte-shifted copies so that every LDS chunk matches a 16-byte ALIGNED global chunk) is
-//     copied with 16-byte LDS writes, fruit and body pixels are painted over it in reference order,
-//     and the image leaves as coalesced 16-byte global stores (1 KiB per wave instruction);
-//   * RNG is Philox4x32-10, one block per 4 draws, evaluated on the scalar unit.
-// Integer / byte work bounded by HBM writes of the observation tensor; no MFMA on purpose.
+//     16 byte-shifted copies so that every LDS chunk equals a 16-byte ALIGNED global chunk) is
+//     copied with 16-byte LDS writes, fruit and body pixels are painted over it in reference
+//     order, and the image leaves as coalesced 16-byte global stores (1 KiB per wave instruction).
+// Integer / byte work bounded by the HBM writes of the observation tensor; no MFMA on purpose.
 //
 // Rules restated (reference paths under /root/reference/src/gym-snake/gym_snake/):
 //   snake_env  : envs/snake_multiple_test.py:97-232         new_world : core/new_world.py:25-158 +
@@ -20,6 +24,7 @@
 //   vec layer  : baselines/common/vec_env/subproc_vec_env.py:13-16, baselines/bench/monitor.py:57-78
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "msnake_internal.h"
 
@@ -32,8 +37,6 @@ __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_bal
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
-// hipcc 7.2 exposes no writelane builtin; a lane-id select does the same job
-#define wrlane(old, sval, l) (lane == (l) ? (uint32_t)(sval) : (uint32_t)(old))
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // lanes of one wave exchange data through LDS: DS operations of a wave execute in program order,
 // this only stops the compiler from moving/forwarding accesses across the exchange point
@@ -45,19 +48,22 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+// lane l <- lane l-1 (lane 0 keeps its value): v_mov_b32 dpp wave_shr:1
+__device__ __forceinline__ uint32_t shift_up1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false);
+}
 
 // ------------------------------------------------------------------------------------------------
-// Philox4x32-10 on wave-uniform operands (rocRAND's seed / subsequence / offset convention)
+// Philox4x32-10 on wave-uniform operands (rocRAND's seed / subsequence / offset convention):
+// draw i of global env g = word (i & 3) of philox(counter = {i>>2, g}, key = seed).
 // ------------------------------------------------------------------------------------------------
-struct Rng {
-    uint32_t k0, k1, e_lo, e_hi;  // key = seed, counter.zw = global env id
-    uint32_t ctr_lo, ctr_hi;      // draws consumed so far
-    uint32_t b0, b1, b2, b3, blk; // cached block
+struct PhiloxBlock {
+    uint32_t b0, b1, b2, b3, blk_lo, blk_hi;
     bool valid;
 };
 
-__device__ __forceinline__ void philox_block(Rng& r, uint32_t c0, uint32_t c1) {
-    uint32_t c2 = r.e_lo, c3 = r.e_hi, k0 = r.k0, k1 = r.k1;
+__device__ __forceinline__ void philox_block(PhiloxBlock& r, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                             uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
@@ -67,21 +73,6 @@ __device__ __forceinline__ void philox_block(Rng& r, uint32_t c0, uint32_t c1) {
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     r.b0 = c0; r.b1 = c1; r.b2 = c2; r.b3 = c3;
-}
-
-// randint(n) = (u32 * n) >> 32 on draw number ctr, then ctr += 1
-__device__ __forceinline__ uint32_t randint(Rng& r, uint32_t n) {
-    const uint32_t blk_lo = (r.ctr_lo >> 2) | (r.ctr_hi << 30), blk_hi = r.ctr_hi >> 2;
-    if (!r.valid || blk_lo != r.blk) {
-        philox_block(r, blk_lo, blk_hi);
-        r.blk = blk_lo;
-        r.valid = true;
-    }
-    const uint32_t sel = r.ctr_lo & 3u;
-    const uint32_t u = sel == 0 ? r.b0 : sel == 1 ? r.b1 : sel == 2 ? r.b2 : r.b3;
-    r.ctr_lo += 1;
-    r.ctr_hi += (r.ctr_lo == 0);
-    return (uint32_t)(((uint64_t)u * n) >> 32);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -96,26 +87,34 @@ __device__ __forceinline__ bool in_grid(uint32_t cell, int dim) {
     return r >= 1 && r <= (uint32_t)dim && c >= 1 && c <= (uint32_t)dim;
 }
 
-// The step kernel. RESET_ONLY = msnake_reset / msnake_render (no game logic).
-//   mode 0: step, 1: reset every env, 2: render only
-template <int RULES, int MODE>
+#define HV_SET(idx, val) hv = (lane == (idx)) ? (uint32_t)(val) : hv
+
+// MODE 0: step, 1: reset every env (msnake_reset), 2: render only (msnake_render)
+template <int RULES, int NS, int MODE>
 __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const StepParams p) {
+    constexpr int VIEWS = RULES == MSNAKE_RULES_NEW_WORLD ? NS : 3;
+    constexpr int C = 3 * VIEWS;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = (int)uni(threadIdx.x >> 6);
     const int e = (int)(blockIdx.x * (blockDim.x >> 6)) + wave;
     if (e >= p.nenv) return;
 
-    const int ns = p.n_snakes, nf = p.n_fruits, dim = p.dim, W = dim + 2, C = p.C, cap = p.cap;
+    const int nf = p.n_fruits, dim = p.dim, W = dim + 2, cap = p.cap;
     const int n2 = dim * dim;
     uint8_t* img = smem + (size_t)wave * p.lds_per_wave;
     uint8_t* occ = img + p.occ_off;
 
-    // ---- 0. independent loads: header, actions, background image ----------------------------
+    // ---- 0. every load whose address depends only on the env index -------------------------------
     uint32_t* hdr_g = p.hdr + (size_t)e * MSNAKE_HDR_WORDS;
-    uint32_t hv = hdr_g[lane];  // lane l holds header word l; lanes 32+f hold fruit f
+    uint16_t* body0_g = p.body0 + (size_t)e * NS * 64;
+    uint16_t* ring_g = p.ring + (size_t)e * NS * cap;
+    uint32_t hv = hdr_g[lane];  // THE env record: lane l holds word l; lanes 32+f hold fruit f
+    uint32_t cr[NS];            // cr[s], lane l: piece l of snake s (valid while l < len)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) cr[s] = body0_g[s * 64 + lane];
     int actv = 0;
-    if (MODE == 0 && lane < ns) actv = p.actions[(size_t)e * p.action_stride + lane];
+    if (MODE == 0 && lane < NS) actv = p.actions[(size_t)e * p.action_stride + lane];
 
     uint8_t* obs_env = p.obs ? p.obs + (size_t)e * p.S : nullptr;
     const uint32_t a = (uint32_t)((uintptr_t)obs_env & 15u);  // misalignment of this env's image
@@ -123,6 +122,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
     const int nchunks = (int)((a + (uint32_t)p.S + 15u) >> 4);
     if (p.obs) {
         const uint4* tsrc = reinterpret_cast<const uint4*>(p.tmpl + (size_t)a * p.tmpl_stride);
+        uint4* dst = reinterpret_cast<uint4*>(img);
         for (int k0 = 0; k0 < nchunks; k0 += 256) {
             uint4 t0, t1, t2, t3;
             const int ka = k0 + lane, kb = ka + 64, kc = ka + 128, kd = ka + 192;
@@ -130,7 +130,6 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
             if (kb < nchunks) t1 = tsrc[kb];
             if (kc < nchunks) t2 = tsrc[kc];
             if (kd < nchunks) t3 = tsrc[kd];
-            uint4* dst = reinterpret_cast<uint4*>(img);
             if (ka < nchunks) dst[ka] = t0;
             if (kb < nchunks) dst[kb] = t1;
             if (kc < nchunks) dst[kc] = t2;
@@ -138,86 +137,54 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
         }
     }
 
-    // ---- 1. header -> wave-uniform registers -------------------------------------------------
-    uint32_t t = rdlane(hv, HDR_T);
-    Rng rng;
-    rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
-    {
-        const uint64_t gid = p.env_id_base + (uint64_t)e;
-        rng.e_lo = (uint32_t)gid; rng.e_hi = (uint32_t)(gid >> 32);
-    }
-    rng.ctr_lo = rdlane(hv, HDR_CTR_LO); rng.ctr_hi = rdlane(hv, HDR_CTR_HI);
-    rng.valid = false; rng.blk = 0; rng.b0 = rng.b1 = rng.b2 = rng.b3 = 0;
-    float ep_ret = __uint_as_float(rdlane(hv, HDR_EP_RETURN));
-    uint32_t ep_len = rdlane(hv, HDR_EP_LEN);
-    uint32_t flags = rdlane(hv, HDR_FLAGS);
-    uint32_t err = 0;
-
-    int hp[MSNAKE_MAX_SNAKES], len[MSNAKE_MAX_SNAKES], grow[MSNAKE_MAX_SNAKES];
-    int head[MSNAKE_MAX_SNAKES], vel[MSNAKE_MAX_SNAKES], nvel[MSNAKE_MAX_SNAKES];
-    int shift[MSNAKE_MAX_SNAKES];     // 1 while a snake that will move has not moved yet
-    bool stored[MSNAKE_MAX_SNAKES];   // new head must be written to the ring
-    uint32_t cellreg[MSNAKE_MAX_SNAKES];  // lane l: piece (l - shift) of snake s (chunk 0)
-    uint16_t* ring_g = p.ring + (size_t)e * ns * cap;
-
-#pragma unroll
-    for (int s = 0; s < MSNAKE_MAX_SNAKES; ++s) {
-        hp[s] = len[s] = grow[s] = head[s] = vel[s] = nvel[s] = shift[s] = 0;
-        stored[s] = false;
-        cellreg[s] = MSNAKE_NO_CELL;
-        if (s < ns) {
-            const uint32_t w0 = rdlane(hv, HDR_SNAKE0 + 4 * s), w2 = rdlane(hv, HDR_SNAKE0 + 4 * s + 2);
-            hp[s] = (int)(w0 & 0xFFFFu); len[s] = (int)(w0 >> 16);
-            grow[s] = (int)rdlane(hv, HDR_SNAKE0 + 4 * s + 1);
-            head[s] = (int)(w2 & 0xFFFFu); vel[s] = (int)((w2 >> 16) & 7u);
-            nvel[s] = vel[s];
-            if (MODE == 0 && len[s] > 0) {
-                // turn now (depends only on this snake): [S]:108-115 == [N]:34-41 == [A]:106-113
-                const int act = (int)rdlane((uint32_t)actv, s);
-                if (act >= 1 && act <= 4 && vel[s] != ((act + 1) & 3) + 1) nvel[s] = act;
-                // snake_env moves only with a non-zero velocity ([S]:119); new_world always
-                // inserts a head, even a duplicate of itself ([N]:43-48,153)
-                shift[s] = (RULES == MSNAKE_RULES_NEW_WORLD) ? 1 : (nvel[s] != 0);
-            }
-            // body chunk 0: lane l <- piece (l - shift) of the PRE-move body
-            const int q = lane - shift[s];
-            if (q >= 0 && q < len[s]) {
-                int idx = hp[s] + q;
-                idx = idx >= cap ? idx - cap : idx;
-                cellreg[s] = ring_g[(size_t)s * cap + idx];
-            }
+    // ---- RNG: randint(n) = (u32 * n) >> 32 on draw number ctr (kept in the record) ---------------
+    PhiloxBlock pb;
+    pb.valid = false; pb.b0 = pb.b1 = pb.b2 = pb.b3 = pb.blk_lo = pb.blk_hi = 0;
+    auto randint = [&](uint32_t n) -> uint32_t {
+        const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
+        const uint32_t blk_lo = (ctr_lo >> 2) | (ctr_hi << 30), blk_hi = ctr_hi >> 2;
+        if (!pb.valid || blk_lo != pb.blk_lo || blk_hi != pb.blk_hi) {
+            const uint64_t gid = p.env_id_base + (uint64_t)e;
+            philox_block(pb, blk_lo, blk_hi, (uint32_t)gid, (uint32_t)(gid >> 32), p.seed_lo, p.seed_hi);
+            pb.blk_lo = blk_lo; pb.blk_hi = blk_hi; pb.valid = true;
         }
-    }
+        const uint32_t sel = ctr_lo & 3u;
+        const uint32_t u = sel == 0 ? pb.b0 : sel == 1 ? pb.b1 : sel == 2 ? pb.b2 : pb.b3;
+        const uint32_t nlo = ctr_lo + 1;
+        HV_SET(HDR_CTR_LO, nlo);
+        HV_SET(HDR_CTR_HI, ctr_hi + (nlo == 0));
+        return (uint32_t)(((uint64_t)u * n) >> 32);
+    };
 
-    // piece iterator: f(i, cell) for every piece i of snake s in its CURRENT logical state
-    auto for_each_piece = [&](int s_hp, int s_len, int s_shift, uint32_t s_reg, const uint16_t* s_ring, auto&& f) {
-        const int i0 = lane - s_shift;
-        if (i0 >= 0 && i0 < s_len) f(i0, s_reg);
-        for (int base = 64 - s_shift; base < s_len; base += 64) {
+    // ---- per-piece visitor: f(i, cell) for every piece i of snake s (chunk 0 from registers,
+    //      pieces >= 64 from the ring) ----------------------------------------------------------
+    auto for_each_piece = [&](int s, uint32_t reg, int s_hp, int s_len, auto&& f) {
+        if (lane < s_len) f(lane, reg);
+        for (int base = 64; base < s_len; base += 64) {  // long bodies only
             const int i = base + lane;
             if (i < s_len) {
                 int idx = s_hp + i;
                 idx = idx >= cap ? idx - cap : idx;
-                f(i, (uint32_t)s_ring[idx]);
+                f(i, (uint32_t)ring_g[(size_t)s * cap + idx]);
             }
         }
     };
 
-    // ---- fruit respawn: [S]:202-217 safe_choose_cell == [N]:235-247 get_safe_cell ------------
+    // ---- fruit respawn: [S]:202-217 safe_choose_cell == [N]:235-247 get_safe_cell --------------
     uint64_t freemask = 0;  // lane c: ballot of the free cells of index chunk c
     int nfree = 0;
     auto build_free = [&]() {
         for (int i = lane * 4; i < p.occ_bytes; i += 256) *reinterpret_cast<uint32_t*>(occ + i) = 0u;
         wave_sync();
 #pragma unroll
-        for (int j = 0; j < MSNAKE_MAX_SNAKES; ++j)
-            if (j < ns && len[j] > 0)
-                for_each_piece(hp[j], len[j], shift[j], cellreg[j], ring_g + (size_t)j * cap,
-                               [&](int, uint32_t cell) {
-                                   // used = c1*dim + c0; out-of-grid heads alias or fall outside
-                                   const int used = ((int)(cell & 255u) - 1) * dim + ((int)(cell >> 8) - 1);
-                                   if ((uint32_t)used < (uint32_t)n2) occ[used] = 1;
-                               });
+        for (int j = 0; j < NS; ++j) {
+            const uint32_t w0 = rdlane(hv, HDR_SNAKE0 + 4 * j);
+            for_each_piece(j, cr[j], (int)(w0 & 0xFFFFu), (int)(w0 >> 16), [&](int, uint32_t cell) {
+                // used = c1*dim + c0; out-of-grid heads alias onto other cells or fall outside
+                const int used = ((int)(cell & 255u) - 1) * dim + ((int)(cell >> 8) - 1);
+                if ((uint32_t)used < (uint32_t)n2) occ[used] = 1;
+            });
+        }
         wave_sync();
         nfree = 0; freemask = 0;
         for (int c = 0; c * 64 < n2; ++c) {
@@ -231,7 +198,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
     auto safe_cell = [&]() -> uint32_t {
         int x = 0;
         if (nfree > 0) {
-            int k = (int)randint(rng, (uint32_t)nfree);
+            int k = (int)randint((uint32_t)nfree);
             for (int c = 0; c * 64 < n2; ++c) {
                 const uint64_t m = ((uint64_t)rdlane((uint32_t)(freemask >> 32), c) << 32) |
                                    rdlane((uint32_t)freemask, c);
@@ -247,161 +214,178 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
         return (uint32_t)(((x % dim + 1) << 8) | (x / dim + 1));
     };
 
-    float reward = 0.0f;
-    bool done = false;
-    int num_alive = 0;
-
     // ---- reset: [S]:219-232 / [NE]:27-33 -> [N]:55-73 ------------------------------------------
     auto do_reset = [&]() {
+        if (RULES == MSNAKE_RULES_NEW_WORLD) {  // bodies must be empty while the first ones are placed
 #pragma unroll
-        for (int s = 0; s < MSNAKE_MAX_SNAKES; ++s)
-            if (s < ns) { len[s] = 0; shift[s] = 0; }
+            for (int s = 0; s < NS; ++s) HV_SET(HDR_SNAKE0 + 4 * s, 0u);
+        }
 #pragma unroll
-        for (int s = 0; s < MSNAKE_MAX_SNAKES; ++s)
-            if (s < ns) {
-                const uint32_t c0 = randint(rng, (uint32_t)dim), c1 = randint(rng, (uint32_t)dim);
-                head[s] = (int)(((c0 + 1) << 8) | (c1 + 1));
-                hp[s] = 0; len[s] = 1; vel[s] = 0; grow[s] = 3; stored[s] = true;
-                cellreg[s] = lane == 0 ? (uint32_t)head[s] : MSNAKE_NO_CELL;
-                if (RULES != MSNAKE_RULES_NEW_WORLD) {  // snake cell, then its fruit, unconstrained
-                    const uint32_t f0 = randint(rng, (uint32_t)dim), f1 = randint(rng, (uint32_t)dim);
-                    if (lane == 32 + s) hv = ((f0 + 1) << 8) | (f1 + 1);
-                }
+        for (int s = 0; s < NS; ++s) {
+            const uint32_t c0 = randint((uint32_t)dim), c1 = randint((uint32_t)dim);
+            const uint32_t hd = ((c0 + 1) << 8) | (c1 + 1);
+            HV_SET(HDR_SNAKE0 + 4 * s, 1u << 16);   // head_pos 0, len 1
+            HV_SET(HDR_SNAKE0 + 4 * s + 1, 3u);     // grow_to 3
+            HV_SET(HDR_SNAKE0 + 4 * s + 2, hd);     // head cell, velocity (0,0)
+            cr[s] = hd;
+            if (lane == 0) ring_g[(size_t)s * cap] = (uint16_t)hd;
+            if (RULES != MSNAKE_RULES_NEW_WORLD) {  // snake cell, then its fruit, unconstrained
+                const uint32_t f0 = randint((uint32_t)dim), f1 = randint((uint32_t)dim);
+                HV_SET(HDR_FRUIT0 + s, ((f0 + 1) << 8) | (f1 + 1));
             }
+        }
         if (RULES == MSNAKE_RULES_NEW_WORLD) {  // all snakes first, then n_fruits safe cells
             build_free();
             for (int f = 0; f < nf; ++f) {
                 const uint32_t c = safe_cell();
-                if (lane == 32 + f) hv = c;
+                HV_SET(HDR_FRUIT0 + f, c);
             }
         }
-        t = 0;
-        flags = (1u << ns) - 1u;  // alive bits set, dead_snakes empty
+        HV_SET(HDR_T, 0u);
+        HV_SET(HDR_FLAGS, (1u << NS) - 1u);  // alive bits set, dead_snakes empty
     };
 
     if (MODE == 1) {
         do_reset();
-        ep_ret = 0.0f; ep_len = 0;
+        HV_SET(HDR_EP_RETURN, 0u);
+        HV_SET(HDR_EP_LEN, 0u);
     }
 
     if (MODE == 0) {
-        // ---- 2. sequential snake updates (order matters: respawn sees earlier snakes moved) ---
-#pragma unroll
-        for (int s = 0; s < MSNAKE_MAX_SNAKES; ++s) {
-            if (s < ns && len[s] > 0 && shift[s] != 0) {
-                const int nh = head[s] + cell_step(nvel[s]);
-                // fruits equal to the new head, as a bit mask over fruit indices
-                const uint64_t em = ballot(lane >= 32 && lane < 32 + nf && (hv & 0xFFFFu) == (uint32_t)nh) >> 32;
-                int g = grow[s], l = len[s];
-                if (RULES == MSNAKE_RULES_NEW_WORLD) {
-                    // [N]:143-150: the pop test sits inside the per-fruit loop
-                    for (int f = 0; f < nf; ++f) {
-                        if ((em >> f) & 1ull) g += 2;
-                        if (l >= g) l -= 1;
-                    }
-                } else {
-                    g += 2 * __builtin_popcountll(em);  // [S]:126-132
-                    if (l >= g) l -= 1;                 // [S]:134-135
+        float reward = 0.0f;
+        // ---- 1. sequential snake updates (order matters: a respawn sees earlier snakes moved,
+        //         a later snake can eat a fruit respawned this very step) -----------------------
+#pragma nounroll
+        for (int s = 0; s < NS; ++s) {  // a real loop: the slow path below exists once in the code
+            const int b = HDR_SNAKE0 + 4 * s;
+            const uint32_t w0 = rdlane(hv, b), w2 = rdlane(hv, b + 2);
+            int len = (int)(w0 >> 16);
+            if (len == 0) continue;
+            const int vel = (int)((w2 >> 16) & 7u), head = (int)(w2 & 0xFFFFu);
+            const int act = (int)rdlane((uint32_t)actv, s);
+            // turn unless it is a 180-degree reversal: [S]:108-115 == [N]:34-41 == [A]:106-113
+            const int nvel = (act >= 1 && act <= 4 && vel != ((act + 1) & 3) + 1) ? act : vel;
+            // snake_env moves only with a velocity ([S]:119); new_world always inserts a head,
+            // even a duplicate of itself ([N]:43-48,153)
+            if (RULES != MSNAKE_RULES_NEW_WORLD && nvel == 0) continue;
+            const int nh = head + cell_step(nvel);
+            // fruits equal to the new head, as a bit mask over fruit indices
+            const uint64_t em = ballot(lane >= 32 && lane < 32 + nf && (hv & 0xFFFFu) == (uint32_t)nh) >> 32;
+            int g = (int)rdlane(hv, b + 1);
+            if (RULES == MSNAKE_RULES_NEW_WORLD) {
+                for (int f = 0; f < nf; ++f) {  // [N]:143-150: the pop test sits inside the fruit loop
+                    if ((em >> f) & 1ull) g += 2;
+                    if (len >= g) len -= 1;
                 }
-                // insert(0, head)
-                l += 1;
-                if (l > cap - 1) { l = cap - 1; err = 1; }
-                hp[s] = hp[s] == 0 ? cap - 1 : hp[s] - 1;
-                len[s] = l; head[s] = nh; grow[s] = g; vel[s] = nvel[s];
-                shift[s] = 0; stored[s] = true;
-                if (lane == 0) cellreg[s] = (uint32_t)nh;
-                if (s == 0) reward = (float)__builtin_popcountll(em);
-                if (em != 0) {  // slow path: respawn each eaten fruit, in index order
-                    build_free();
-                    uint64_t m = em;
-                    while (m) {
-                        const int f = __builtin_ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        const uint32_t c = safe_cell();
-                        if (lane == 32 + f) hv = c;
-                    }
+            } else {
+                g += 2 * __builtin_popcountll(em);  // [S]:126-132
+                if (len >= g) len -= 1;             // [S]:134-135
+            }
+            len += 1;  // insert(0, head)
+            if (len > cap - 1) { len = cap - 1; if (lane == 0) atomicAdd(&p.stats[4], 1ull); }
+            int hp = (int)(w0 & 0xFFFFu);
+            hp = hp == 0 ? cap - 1 : hp - 1;
+            HV_SET(b, (uint32_t)hp | ((uint32_t)len << 16));
+            HV_SET(b + 1, (uint32_t)g);
+            HV_SET(b + 2, (uint32_t)nh | ((uint32_t)nvel << 16));
+            if (lane == 0) ring_g[(size_t)s * cap + hp] = (uint16_t)nh;
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+                if (j == s) {
+                    const uint32_t sh = shift_up1(cr[j]);
+                    cr[j] = lane == 0 ? (uint32_t)nh : sh;
+                }
+            if (s == 0) reward = (float)__builtin_popcountll(em);
+            if (em != 0) {  // slow path: respawn each eaten fruit, in index order
+                build_free();
+                uint64_t m = em;
+                while (m) {
+                    const int f = __builtin_ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const uint32_t c = safe_cell();
+                    HV_SET(HDR_FRUIT0 + f, c);
                 }
             }
         }
 
-        // ---- 3. head-vs-piece matrix: hit[s][j] = some piece of j (other than s's own head)
-        //         lies on s's head ------------------------------------------------------------
-        bool hitl[MSNAKE_MAX_SNAKES][MSNAKE_MAX_SNAKES];
+        // ---- 2. head-vs-piece matrix: bit (4*s + j) of `hits` = some piece of snake j other
+        //         than s's own head lies on s's head -------------------------------------------
+        uint32_t hd[NS], ln[NS], hp2[NS];
 #pragma unroll
-        for (int s = 0; s < MSNAKE_MAX_SNAKES; ++s)
+        for (int s = 0; s < NS; ++s) {
+            const uint32_t w0 = rdlane(hv, HDR_SNAKE0 + 4 * s);
+            hd[s] = rdlane(hv, HDR_SNAKE0 + 4 * s + 2) & 0xFFFFu;
+            ln[s] = w0 >> 16; hp2[s] = w0 & 0xFFFFu;
+        }
+        uint32_t hitl = 0;  // per-lane accumulation
 #pragma unroll
-            for (int j = 0; j < MSNAKE_MAX_SNAKES; ++j) hitl[s][j] = false;
+        for (int j = 0; j < NS; ++j)
+            for_each_piece(j, cr[j], (int)hp2[j], (int)ln[j], [&](int i, uint32_t cell) {
 #pragma unroll
-        for (int j = 0; j < MSNAKE_MAX_SNAKES; ++j)
-            if (j < ns && len[j] > 0)
-                for_each_piece(hp[j], len[j], shift[j], cellreg[j], ring_g + (size_t)j * cap,
-                               [&](int i, uint32_t cell) {
+                for (int s = 0; s < NS; ++s)
+                    if (cell == hd[s] && !(j == s && i == 0)) hitl |= 1u << (4 * s + j);
+            });
+        uint32_t hits = 0;
 #pragma unroll
-                                   for (int s = 0; s < MSNAKE_MAX_SNAKES; ++s)
-                                       if (s < ns)
-                                           hitl[s][j] |= (cell == (uint32_t)head[s]) && !(j == s && i == 0);
-                               });
-        bool hit[MSNAKE_MAX_SNAKES][MSNAKE_MAX_SNAKES];
+        for (int s = 0; s < NS; ++s) {
+            if (RULES == MSNAKE_RULES_NEW_WORLD) {
 #pragma unroll
-        for (int s = 0; s < MSNAKE_MAX_SNAKES; ++s)
-#pragma unroll
-            for (int j = 0; j < MSNAKE_MAX_SNAKES; ++j)
-                hit[s][j] = (s < ns && j < ns && len[s] > 0) ? (ballot(hitl[s][j]) != 0) : false;
+                for (int j = 0; j < NS; ++j)
+                    if (ballot((hitl >> (4 * s + j)) & 1u) != 0) hits |= 1u << (4 * s + j);
+            } else {
+                if (ballot(((hitl >> (4 * s)) & 15u) != 0) != 0) hits |= 1u << (4 * s);
+            }
+        }
 
-        // ---- 4. aliveness, reward, done -----------------------------------------------------
+        // ---- 3. aliveness, reward, done --------------------------------------------------------
+        bool done;
+        int num_alive;
+        uint32_t t = rdlane(hv, HDR_T) + 1;
         if (RULES == MSNAKE_RULES_NEW_WORLD) {
             // [N]:101-107 + :111-132: in snake order, clearing bodies as it goes
+            uint32_t flags = rdlane(hv, HDR_FLAGS);
             bool done0 = false;
 #pragma unroll
-            for (int s = 0; s < MSNAKE_MAX_SNAKES; ++s)
-                if (s < ns) {
-                    bool alive;
-                    if (len[s] == 0) alive = false;
-                    else if (!in_grid((uint32_t)head[s], dim)) { len[s] = 0; alive = false; }
-                    else {
-                        bool other = false;
+            for (int s = 0; s < NS; ++s) {
+                bool alive;
+                if (ln[s] == 0) alive = false;
+                else if (!in_grid(hd[s], dim)) { ln[s] = 0; alive = false; }
+                else {
+                    bool other = false;
 #pragma unroll
-                        for (int j = 0; j < MSNAKE_MAX_SNAKES; ++j)
-                            if (j < ns && j != s && len[j] > 0 && hit[s][j]) other = true;
-                        if (other) { len[s] = 0; alive = false; }
-                        else alive = !hit[s][s];  // self hit: not alive, body kept
-                    }
-                    flags = alive ? (flags | (1u << s)) : (flags & ~(1u << s));
-                    if (!alive) flags |= (16u << s);  // dead_snakes, append-once
-                    if (s == 0) done0 = alive;        // [N]:107 (sic)
+                    for (int j = 0; j < NS; ++j)
+                        if (j != s && ln[j] > 0 && ((hits >> (4 * s + j)) & 1u)) other = true;
+                    if (other) { ln[s] = 0; alive = false; }
+                    else alive = !((hits >> (4 * s + s)) & 1u);  // self hit: not alive, body kept
                 }
+                if (ln[s] == 0) HV_SET(HDR_SNAKE0 + 4 * s, hp2[s]);
+                flags = alive ? (flags | (1u << s)) : (flags & ~(1u << s));
+                if (!alive) flags |= (16u << s);  // dead_snakes, append-once
+                if (s == 0) done0 = alive;        // [N]:107 (sic)
+            }
+            HV_SET(HDR_FLAGS, flags);
             if (done0) reward = -1.0f;  // [NE]:39-40
-            t += 1;
             done = (t >= (uint32_t)p.max_steps) || done0;
-            num_alive = ns - __builtin_popcount((flags >> 4) & 15u);
+            num_alive = NS - __builtin_popcount((flags >> 4) & 15u);
         } else {
             // [S]:178-197: simultaneous
-            bool dead[MSNAKE_MAX_SNAKES];
             int ndead = 0;
 #pragma unroll
-            for (int s = 0; s < MSNAKE_MAX_SNAKES; ++s) {
-                dead[s] = false;
-                if (s < ns) {
-                    bool any = false;
-#pragma unroll
-                    for (int j = 0; j < MSNAKE_MAX_SNAKES; ++j) any |= hit[s][j];
-                    dead[s] = len[s] == 0 || !in_grid((uint32_t)head[s], dim) || any;
-                    ndead += dead[s];
-                }
+            for (int s = 0; s < NS; ++s) {
+                const bool dead = ln[s] == 0 || !in_grid(hd[s], dim) || ((hits >> (4 * s)) & 1u);
+                ndead += dead;
+                if (dead) { ln[s] = 0; HV_SET(HDR_SNAKE0 + 4 * s, hp2[s]); }
             }
-#pragma unroll
-            for (int s = 0; s < MSNAKE_MAX_SNAKES; ++s)
-                if (s < ns && dead[s]) len[s] = 0;
-            const bool main_dead = len[0] == 0;
+            const bool main_dead = ln[0] == 0;
             if (main_dead) reward = -1.0f;
-            t += 1;
             done = (t >= (uint32_t)p.max_steps) || main_dead;
-            num_alive = ns - ndead;
+            num_alive = NS - ndead;
         }
+        HV_SET(HDR_T, t);
 
-        // ---- 5. vec layer: episode statistics and auto reset ---------------------------------
-        ep_ret += reward;
-        ep_len += 1;
+        // ---- 4. vec layer: episode statistics and auto reset -----------------------------------
+        float ep_ret = __uint_as_float(rdlane(hv, HDR_EP_RETURN)) + reward;
+        uint32_t ep_len = rdlane(hv, HDR_EP_LEN) + 1;
         float out_ret = 0.0f;
         uint32_t out_len = 0;
         if (done) {
@@ -416,6 +400,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
                 do_reset();
             }
         }
+        HV_SET(HDR_EP_RETURN, __float_as_uint(ep_ret));
+        HV_SET(HDR_EP_LEN, ep_len);
         if (lane == 0) {
             p.rew[e] = reward;
             p.done[e] = done ? 1 : 0;
@@ -424,8 +410,14 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
                 iv.x = (int)__float_as_uint(out_ret); iv.y = (int)out_len; iv.z = num_alive; iv.w = done ? 1 : 0;
                 reinterpret_cast<int4*>(p.info)[e] = iv;
             }
-            if (err) atomicAdd(&p.stats[4], 1ull);
         }
+    }
+
+    // ---- 5. state write-back (fire and forget, overlaps the painting) ---------------------------
+    if (MODE != 2) {
+        hdr_g[lane] = hv;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) body0_g[s * 64 + lane] = (uint16_t)cr[s];
     }
 
     // ---- 6. paint the observation over the background, in reference order ----------------------
@@ -437,27 +429,29 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
             const uint32_t cell = hv & 0xFFFFu;
             if (in_grid(cell, dim)) {
                 const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * C;
-                for (int v = 0; v < p.views; ++v) px[off + 3 * v] = 255;
+#pragma unroll
+                for (int v = 0; v < VIEWS; ++v) px[off + 3 * v] = 255;
             }
         }
         // snakes in index order, head over body ([S]:46-50, draw_snake :24-33)
+        const uint32_t flags = rdlane(hv, HDR_FLAGS);
 #pragma unroll
-        for (int j = 0; j < MSNAKE_MAX_SNAKES; ++j) {
-            if (j < ns && len[j] > 0 && (RULES != MSNAKE_RULES_NEW_WORLD || ((flags >> j) & 1u))) {
-                for_each_piece(hp[j], len[j], shift[j], cellreg[j], ring_g + (size_t)j * cap,
-                               [&](int i, uint32_t cell) {
-                                   if (!in_grid(cell, dim)) return;
-                                   const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * C;
-                                   const bool hd = i == 0;
-                                   for (int v = 0; v < p.views; ++v) {
-                                       const bool self = v == j;
-                                       // body/head: self green (0,204,0)/(191,242,191), other blue (0,51,204)/(128,154,230)
-                                       px[off + 3 * v + 0] = hd ? (self ? 191 : 128) : 0;
-                                       px[off + 3 * v + 1] = hd ? (self ? 242 : 154) : (self ? 204 : 51);
-                                       px[off + 3 * v + 2] = hd ? (self ? 191 : 230) : (self ? 0 : 204);
-                                   }
-                               });
-            }
+        for (int j = 0; j < NS; ++j) {
+            const uint32_t w0 = rdlane(hv, HDR_SNAKE0 + 4 * j);
+            if (RULES == MSNAKE_RULES_NEW_WORLD && !((flags >> j) & 1u)) continue;  // [N]:219
+            for_each_piece(j, cr[j], (int)(w0 & 0xFFFFu), (int)(w0 >> 16), [&](int i, uint32_t cell) {
+                if (!in_grid(cell, dim)) return;
+                const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * C;
+                const bool hd1 = i == 0;
+#pragma unroll
+                for (int v = 0; v < VIEWS; ++v) {
+                    // body/head: self green (0,204,0)/(191,242,191), other blue (0,51,204)/(128,154,230)
+                    const bool self = v == j;
+                    px[off + 3 * v + 0] = hd1 ? (self ? 191 : 128) : 0;
+                    px[off + 3 * v + 1] = hd1 ? (self ? 242 : 154) : (self ? 204 : 51);
+                    px[off + 3 * v + 2] = hd1 ? (self ? 191 : 230) : (self ? 0 : 204);
+                }
+            });
         }
         wave_sync();
         // ---- 7. LDS image -> HBM: 16-byte aligned chunks, 1 KiB per wave instruction ----------
@@ -474,41 +468,35 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
             if (!full && b >= lo_b && b < hi_b) obs_al[b] = img[b];
         }
     }
-
-    // ---- 8. state write-back --------------------------------------------------------------------
-    if (MODE != 2) {
-#pragma unroll
-        for (int s = 0; s < MSNAKE_MAX_SNAKES; ++s)
-            if (s < ns) {
-                if (stored[s] && lane == 0) ring_g[(size_t)s * cap + hp[s]] = (uint16_t)head[s];
-                hv = wrlane(hv, (uint32_t)hp[s] | ((uint32_t)len[s] << 16), HDR_SNAKE0 + 4 * s);
-                hv = wrlane(hv, (uint32_t)grow[s], HDR_SNAKE0 + 4 * s + 1);
-                hv = wrlane(hv, (uint32_t)head[s] | ((uint32_t)vel[s] << 16), HDR_SNAKE0 + 4 * s + 2);
-            }
-        hv = wrlane(hv, t, HDR_T);
-        hv = wrlane(hv, rng.ctr_lo, HDR_CTR_LO);
-        hv = wrlane(hv, rng.ctr_hi, HDR_CTR_HI);
-        hv = wrlane(hv, __float_as_uint(ep_ret), HDR_EP_RETURN);
-        hv = wrlane(hv, ep_len, HDR_EP_LEN);
-        hv = wrlane(hv, flags, HDR_FLAGS);
-        hdr_g[lane] = hv;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // launch glue (called from the C-ABI in msnake_capi.hip)
 // ------------------------------------------------------------------------------------------------
-template <int RULES>
-static hipError_t launch_rules(const StepParams& p, int mode, int epb, hipStream_t stream) {
+template <int RULES, int NS>
+static hipError_t launch_ns(const StepParams& p, int mode, int epb, hipStream_t stream) {
     const dim3 grid((unsigned)((p.nenv + epb - 1) / epb));
     const dim3 block(64u * (unsigned)epb);
     const size_t lds = (size_t)p.lds_per_wave * (size_t)epb;
     switch (mode) {
-        case 0: hipLaunchKernelGGL((msnake_step_kernel<RULES, 0>), grid, block, lds, stream, p); break;
-        case 1: hipLaunchKernelGGL((msnake_step_kernel<RULES, 1>), grid, block, lds, stream, p); break;
-        default: hipLaunchKernelGGL((msnake_step_kernel<RULES, 2>), grid, block, lds, stream, p); break;
+        case 0: hipLaunchKernelGGL((msnake_step_kernel<RULES, NS, 0>), grid, block, lds, stream, p); break;
+        case 1: hipLaunchKernelGGL((msnake_step_kernel<RULES, NS, 1>), grid, block, lds, stream, p); break;
+        default: hipLaunchKernelGGL((msnake_step_kernel<RULES, NS, 2>), grid, block, lds, stream, p); break;
     }
     return hipGetLastError();
+}
+
+template <int RULES>
+static hipError_t launch_rules(const StepParams& p, int mode, int epb, hipStream_t stream) {
+    switch (p.n_snakes) {
+        case 1: return launch_ns<RULES, 1>(p, mode, epb, stream);
+        case 2: return launch_ns<RULES, 2>(p, mode, epb, stream);
+        case 3: return launch_ns<RULES, 3>(p, mode, epb, stream);
+        case 4:
+            if (RULES == MSNAKE_RULES_NEW_WORLD) return launch_ns<MSNAKE_RULES_NEW_WORLD, 4>(p, mode, epb, stream);
+            return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_step(const StepParams& p, int rules, int mode, int epb, hipStream_t stream) {
@@ -520,8 +508,10 @@ hipError_t launch_step(const StepParams& p, int rules, int mode, int epb, hipStr
     }
 }
 
-const char* step_kernel_name(int rules) {
-    return rules == MSNAKE_RULES_NEW_WORLD ? "msnake_step_kernel<1, 0>" : "msnake_step_kernel<0, 0>";
+static char g_kname[64];
+const char* step_kernel_name(int rules, int n_snakes) {
+    snprintf(g_kname, sizeof(g_kname), "msnake_step_kernel<%d, %d, 0>", rules, n_snakes);
+    return g_kname;
 }
 
 }  // namespace msnake
