@@ -8,6 +8,8 @@ imported from here.
 """
 from . import _capi
 from .spaces import Box, Discrete
+from .dist import gather_stats, make_sharded, shard_range
 from .vec_env import GYM_IDS, LazyInfos, MultiSnakeVecEnv, make, normalize_actions
 
-__all__ = ["MultiSnakeVecEnv", "make", "GYM_IDS", "LazyInfos", "normalize_actions", "Box", "Discrete", "_capi"]
+__all__ = ["MultiSnakeVecEnv", "make", "GYM_IDS", "LazyInfos", "normalize_actions", "Box", "Discrete", "_capi",
+           "shard_range", "gather_stats", "make_sharded"]

@@ -131,32 +131,30 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
     p.views = cfg->rules == MSNAKE_RULES_NEW_WORLD ? cfg->n_snakes : 3;
     p.C = 3 * p.views;
     p.S = W * W * p.C;
-    p.max_steps = cfg->max_steps;
+    p.rest.max_steps = cfg->max_steps;
     p.auto_reset = cfg->auto_reset ? 1 : 0;
     // ring capacity: snake_env bodies hold distinct in-grid cells plus one transient head;
     // new_world bodies can stack duplicates and are only bounded by the episode length
     int need = n2 + 2;
     if (cfg->rules == MSNAKE_RULES_NEW_WORLD && cfg->max_steps + 2 > need) need = cfg->max_steps + 2;
-    p.cap = (need + 63) / 64 * 64;
-    const int nchunks_max = (15 + p.S + 15) >> 4;
-    p.tmpl_stride = nchunks_max * 16;
-    p.occ_off = p.tmpl_stride;
-    p.occ_bytes = (n2 + 15) / 16 * 16;
-    p.lds_per_wave = p.occ_off + p.occ_bytes;
-    p.seed_lo = (uint32_t)cfg->seed;
-    p.seed_hi = (uint32_t)(cfg->seed >> 32);
-    p.env_id_base = cfg->env_id_base;
+    p.rest.cap = (need + 63) / 64 * 64;
+    p.img_bytes = (p.S + 1023) / 1024 * 1024;  // whole 1 KiB wave-instructions, no lane predicates
+    p.rest.occ_bytes = (n2 + 15) / 16 * 16;
+    p.lds_per_wave = p.img_bytes + p.rest.occ_bytes;
+    p.rest.seed_lo = (uint32_t)cfg->seed;
+    p.rest.seed_hi = (uint32_t)(cfg->seed >> 32);
+    p.rest.env_id_base = cfg->env_id_base;
     h->epb = MSNAKE_MAX_ENVS_PER_BLOCK;
     while (h->epb > 1 && (size_t)h->epb * p.lds_per_wave > 64 * 1024) h->epb >>= 1;
-    if ((size_t)p.lds_per_wave > 64 * 1024) {
+    if ((size_t)p.lds_per_wave > 64 * 1024 - 16 || p.S > 0xFFFF) {
         free(h);
         return fail(MSNAKE_E_ARG, "observation image of %d bytes does not fit in LDS", p.S);
     }
 
     const size_t hdr_bytes = (size_t)p.nenv * MSNAKE_HDR_WORDS * 4;
-    const size_t ring_bytes = (size_t)p.nenv * p.n_snakes * p.cap * 2;
+    const size_t ring_bytes = (size_t)p.nenv * p.n_snakes * p.rest.cap * 2;
     const size_t body0_bytes = (size_t)p.nenv * p.n_snakes * 64 * 2;
-    const size_t tmpl_bytes = (size_t)16 * p.tmpl_stride;
+    const size_t tmpl_bytes = (size_t)p.img_bytes;
     hipError_t e;
     if ((e = hipMalloc(&h->d_hdr, hdr_bytes)) != hipSuccess || (e = hipMalloc(&h->d_ring, ring_bytes)) != hipSuccess ||
         (e = hipMalloc(&h->d_body0, body0_bytes)) != hipSuccess || (e = hipMemset(h->d_body0, 0, body0_bytes)) != hipSuccess ||
@@ -168,24 +166,22 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
         return fail(MSNAKE_E_HIP, "allocating %zu bytes of env state failed: %s", hdr_bytes + ring_bytes + tmpl_bytes,
                     hipGetErrorString(e));
     }
-    // background image: black interior, white 1-px wall ring (snake_multiple_test.py:38,52-56),
-    // once per byte misalignment so LDS chunk k always equals aligned global chunk k
+    // background image: black interior, white 1-px wall ring (snake_multiple_test.py:38,52-56)
     std::vector<uint8_t> tmpl(tmpl_bytes, 0);
-    for (int a = 0; a < 16; ++a)
-        for (int r = 0; r < W; ++r)
-            for (int c = 0; c < W; ++c)
-                if (r == 0 || r == W - 1 || c == 0 || c == W - 1)
-                    memset(&tmpl[(size_t)a * p.tmpl_stride + a + ((size_t)r * W + c) * p.C], 255, (size_t)p.C);
+    for (int r = 0; r < W; ++r)
+        for (int c = 0; c < W; ++c)
+            if (r == 0 || r == W - 1 || c == 0 || c == W - 1)
+                memset(&tmpl[((size_t)r * W + c) * p.C], 255, (size_t)p.C);
     if ((e = hipMemcpy(h->d_tmpl, tmpl.data(), tmpl_bytes, hipMemcpyHostToDevice)) != hipSuccess) {
         (void)hipFree(h->d_hdr); (void)hipFree(h->d_body0); (void)hipFree(h->d_ring); (void)hipFree(h->d_tmpl); (void)hipFree(h->d_stats);
         free(h);
         return fail(MSNAKE_E_HIP, "uploading the background image failed: %s", hipGetErrorString(e));
     }
     p.hdr = static_cast<uint32_t*>(h->d_hdr);
-    p.ring = static_cast<uint16_t*>(h->d_ring);
+    p.rest.ring = static_cast<uint16_t*>(h->d_ring);
     p.body0 = static_cast<uint16_t*>(h->d_body0);
     p.tmpl = static_cast<const uint8_t*>(h->d_tmpl);
-    p.stats = static_cast<unsigned long long*>(h->d_stats);
+    p.rest.stats = static_cast<unsigned long long*>(h->d_stats);
     h->magic = kMagic;
     *out = h;
     return MSNAKE_OK;
@@ -213,7 +209,7 @@ static int launch(msnake_handle h, int mode, const int32_t* actions, int32_t act
                   uint8_t* done, msnake_info* info, void* stream) {
     msnake::StepParams p = h->p;
     p.actions = actions; p.action_stride = action_stride;
-    p.obs = obs; p.rew = rew; p.done = done; p.info = info;
+    p.obs = obs; p.rest.rew = rew; p.rest.done = done; p.rest.info = info;
     DeviceGuard guard(h->cfg.device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = msnake::launch_step(p, h->cfg.rules, mode, h->epb, s);
@@ -270,8 +266,8 @@ int msnake_get_state(msnake_handle h, int32_t env, int32_t* words, int32_t cap_w
     const msnake::StepParams& p = h->p;
     uint32_t hdr[MSNAKE_HDR_WORDS];
     HIP_TRY(hipMemcpy(hdr, p.hdr + (size_t)env * MSNAKE_HDR_WORDS, sizeof(hdr), hipMemcpyDeviceToHost));
-    std::vector<uint16_t> ring((size_t)p.n_snakes * p.cap);
-    HIP_TRY(hipMemcpy(ring.data(), p.ring + (size_t)env * p.n_snakes * p.cap, ring.size() * 2, hipMemcpyDeviceToHost));
+    std::vector<uint16_t> ring((size_t)p.n_snakes * p.rest.cap);
+    HIP_TRY(hipMemcpy(ring.data(), p.rest.ring + (size_t)env * p.n_snakes * p.rest.cap, ring.size() * 2, hipMemcpyDeviceToHost));
     int32_t need = 8 + 2 * p.n_fruits;
     for (int s = 0; s < p.n_snakes; ++s) need += 6 + 2 * (int32_t)(hdr[HDR_SNAKE0 + 4 * s] >> 16);
     if (!words || cap_words < need) return need;
@@ -300,7 +296,7 @@ int msnake_get_state(msnake_handle h, int32_t env, int32_t* words, int32_t cap_w
         words[k++] = nw ? (int32_t)((hdr[HDR_FLAGS] >> s) & 1u) : 1;
         words[k++] = nw ? (int32_t)((hdr[HDR_FLAGS] >> (4 + s)) & 1u) : 0;
         for (int i = 0; i < len; ++i) {
-            const uint32_t c = ring[(size_t)s * p.cap + (size_t)((hp + i) % p.cap)];
+            const uint32_t c = ring[(size_t)s * p.rest.cap + (size_t)((hp + i) % p.rest.cap)];
             words[k++] = (int32_t)(c >> 8) - 1;
             words[k++] = (int32_t)(c & 255u) - 1;
         }
@@ -316,7 +312,7 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
     if (words[7] != p.n_snakes) return fail(MSNAKE_E_STATE, "state has %d snakes, handle has %d", words[7], p.n_snakes);
     if (words[6] != p.n_fruits) return fail(MSNAKE_E_STATE, "state has %d fruits, handle has %d", words[6], p.n_fruits);
     uint32_t hdr[MSNAKE_HDR_WORDS] = {0};
-    std::vector<uint16_t> ring((size_t)p.n_snakes * p.cap, 0);
+    std::vector<uint16_t> ring((size_t)p.n_snakes * p.rest.cap, 0);
     std::vector<uint16_t> body0((size_t)p.n_snakes * 64, 0);
     auto cell = [&](int32_t c0, int32_t c1, uint32_t* out) -> bool {
         if (c0 < -1 || c0 > p.dim || c1 < -1 || c1 > p.dim) return false;
@@ -340,12 +336,12 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
         const int len = words[k], v0 = words[k + 1], v1 = words[k + 2], grow = words[k + 3];
         const int alive = words[k + 4], in_dead = words[k + 5];
         k += 6;
-        if (len < 0 || len > p.cap - 2 || n < k + 2 * len) return fail(MSNAKE_E_STATE, "snake %d: bad length %d", s, len);
+        if (len < 0 || len > p.rest.cap - 2 || n < k + 2 * len) return fail(MSNAKE_E_STATE, "snake %d: bad length %d", s, len);
         uint32_t headc = 0;
         for (int i = 0; i < len; ++i, k += 2) {
             uint32_t c;
             if (!cell(words[k], words[k + 1], &c)) return fail(MSNAKE_E_STATE, "snake %d piece %d outside [-1, dim]", s, i);
-            ring[(size_t)s * p.cap + i] = (uint16_t)c;
+            ring[(size_t)s * p.rest.cap + i] = (uint16_t)c;
             if (i < 64) body0[(size_t)s * 64 + i] = (uint16_t)c;
             if (i == 0) headc = c;
         }
@@ -359,7 +355,7 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
     DeviceGuard guard(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(p.hdr + (size_t)env * MSNAKE_HDR_WORDS, hdr, sizeof(hdr), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(p.ring + (size_t)env * p.n_snakes * p.cap, ring.data(), ring.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p.rest.ring + (size_t)env * p.n_snakes * p.rest.cap, ring.data(), ring.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p.body0 + (size_t)env * p.n_snakes * 64, body0.data(), body0.size() * 2, hipMemcpyHostToDevice));
     return MSNAKE_OK;
 }
@@ -368,19 +364,19 @@ int msnake_get_stats(msnake_handle h, msnake_stats* out, int32_t reset) {
     if (int rc = check(h)) return rc;
     if (!out) return fail(MSNAKE_E_ARG, "msnake_get_stats: out is NULL");
     DeviceGuard guard(h->cfg.device);
-    HIP_TRY(hipStreamSynchronize(h->last_stream));
+    // the totals live in the env records; sum (and optionally clear) them behind the last step
+    HIP_TRY(hipMemsetAsync(h->d_stats, 0, 64, h->last_stream));
+    HIP_TRY(msnake::launch_stats(h->p.hdr, h->p.nenv, h->p.rest.stats, reset ? 1 : 0, h->last_stream));
     unsigned long long raw[8];
-    HIP_TRY(hipMemcpy(raw, h->d_stats, sizeof(raw), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(raw, h->d_stats, sizeof(raw), hipMemcpyDeviceToHost, h->last_stream));
+    HIP_TRY(hipStreamSynchronize(h->last_stream));
     memset(out, 0, sizeof(*out));
     out->episodes = (int64_t)raw[0];
     out->ep_len_sum = (int64_t)raw[1];
     out->ep_return_sum = (int64_t)raw[2];
     out->env_steps = h->env_steps;
     out->errors = (int64_t)raw[4];
-    if (reset) {
-        HIP_TRY(hipMemset(h->d_stats, 0, 64));
-        h->env_steps = 0;
-    }
+    if (reset) h->env_steps = 0;
     return MSNAKE_OK;
 }
 

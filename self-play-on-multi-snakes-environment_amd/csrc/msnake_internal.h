@@ -24,36 +24,48 @@
 #define HDR_NLIST 6      // [A] length of the fruit list
 #define HDR_FLAGS 7      // [N] bit s: Snake.alive, bit 4+s: snake in World.dead_snakes
 #define HDR_SNAKE0 8     // 4 words per snake: {ring head pos | len<<16, grow_to, head cell | vel<<16, -}
+#define HDR_ACC_EPISODES 24  // per-env totals since the last msnake_get_stats(reset=1): no hot-path atomics
+#define HDR_ACC_LEN 25
+#define HDR_ACC_RETURN 26    // int32, rewards are integral
+#define HDR_ACC_ERRORS 27
 #define HDR_FRUIT0 32    // word 32+f: fruit f's cell (snake_env / new_world keep fruits inline)
 
 #define MSNAKE_NO_CELL 0xFFFFu  // never equals a real cell (rows/cols <= 63)
 
 namespace msnake {
 
-struct StepParams {
-    // configuration
-    int32_t nenv, dim, n_snakes, n_fruits, views, C, S, max_steps, auto_reset;
-    int32_t cap;           // ring capacity in cells (multiple of 64)
-    int32_t lds_per_wave;  // bytes of LDS per env: image chunks + occupancy bytes
-    int32_t occ_off, occ_bytes;
-    int32_t tmpl_stride;   // bytes between the 16 byte-shifted background images
-    int32_t action_stride;
-    uint32_t seed_lo, seed_hi;
-    uint64_t env_id_base;
-    // state (HBM, owned by the handle)
-    uint32_t* hdr;               // [nenv][64]
-    uint16_t* body0;             // [nenv][n_snakes][64] the first 64 body cells in logical order
+// rarely needed kernel arguments, passed by value behind the preloaded ones
+struct StepRest {
     uint16_t* ring;              // [nenv][n_snakes][cap] every body cell, piece i at (head_pos + i) % cap
-    const uint8_t* tmpl;         // [16][tmpl_stride]
     unsigned long long* stats;   // [8]
-    // per-call i/o (device pointers owned by the caller)
-    const int32_t* actions;
-    uint8_t* obs;
     float* rew;
     uint8_t* done;
     msnake_info* info;
+    uint64_t env_id_base;
+    uint32_t seed_lo, seed_hi;
+    int32_t cap;                 // ring capacity in cells (multiple of 64)
+    int32_t max_steps;
+    int32_t occ_bytes;
+    int32_t reserved;
 };
 
+struct StepParams {
+    // configuration
+    int32_t nenv, dim, n_snakes, n_fruits, views, C, S, auto_reset;
+    int32_t lds_per_wave;  // bytes of LDS per env: padded image + occupancy bytes
+    int32_t img_bytes;     // S rounded up to 1 KiB
+    int32_t action_stride;
+    // state (HBM, owned by the handle)
+    uint32_t* hdr;               // [nenv][64]
+    uint16_t* body0;             // [nenv][n_snakes][64] the first 64 body cells in logical order
+    const uint8_t* tmpl;         // [img_bytes] background image
+    // per-call i/o (device pointers owned by the caller)
+    const int32_t* actions;
+    uint8_t* obs;
+    StepRest rest;
+};
+
+hipError_t launch_stats(uint32_t* hdr, int nenv, unsigned long long* stats, int clear, hipStream_t stream);
 hipError_t launch_step(const StepParams& p, int rules, int mode, int envs_per_block, hipStream_t stream);
 const char* step_kernel_name(int rules, int n_snakes);
 

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "msnake_internal.h"
 
@@ -89,53 +90,65 @@ __device__ __forceinline__ bool in_grid(uint32_t cell, int dim) {
 
 #define HV_SET(idx, val) hv = (lane == (idx)) ? (uint32_t)(val) : hv
 
+typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
+
 // MODE 0: step, 1: reset every env (msnake_reset), 2: render only (msnake_render)
+// The first 13 kernel-argument dwords (pointers + packed configuration) are preloaded into SGPRs
+// by the dispatcher (-mllvm -amdgpu-kernarg-preload-count), so a wave can issue its state loads
+// without waiting for a scalar-memory round trip; the rarely used rest comes by value behind them.
 template <int RULES, int NS, int MODE>
-__global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const StepParams p) {
+__global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
+    uint32_t* __restrict__ hdr, uint16_t* __restrict__ body0, uint8_t* __restrict__ obs,
+    const uint8_t* __restrict__ tmpl, const int32_t* __restrict__ actions, const int32_t nenv, const uint32_t pk0,
+    const uint32_t pk1, const StepRest p) {
     constexpr int VIEWS = RULES == MSNAKE_RULES_NEW_WORLD ? NS : 3;
     constexpr int C = 3 * VIEWS;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = (int)uni(threadIdx.x >> 6);
     const int e = (int)(blockIdx.x * (blockDim.x >> 6)) + wave;
-    if (e >= p.nenv) return;
+    if (e >= nenv) return;
 
-    const int nf = p.n_fruits, dim = p.dim, W = dim + 2, cap = p.cap;
-    const int n2 = dim * dim;
-    uint8_t* img = smem + (size_t)wave * p.lds_per_wave;
-    uint8_t* occ = img + p.occ_off;
+    const int dim = (int)(pk0 & 255u), nf = (int)((pk0 >> 8) & 255u), action_stride = (int)((pk0 >> 16) & 255u);
+    const bool auto_reset = (pk0 >> 24) & 1u;
+    const uint32_t dbg = pk0 >> 25;  // timing-only early exits (MSNAKE_DBG_STAGE), 0 in production
+#define DBG_EXIT(n) if (dbg == (n)) { if (hv == 0xDEADBEEFu) hdr_g[lane] = hv + cr[0]; return; }
+    const int S = (int)(pk1 & 0xFFFFu), lds_per_wave = (int)(pk1 >> 16);
+    const int W = dim + 2, n2 = dim * dim;
+    const int img_bytes = (S + 1023) & ~1023;  // image padded to whole 1 KiB wave-instructions
+    uint8_t* img = smem + (size_t)wave * lds_per_wave;
+    uint8_t* occ = img + img_bytes;
 
     // ---- 0. every load whose address depends only on the env index -------------------------------
-    uint32_t* hdr_g = p.hdr + (size_t)e * MSNAKE_HDR_WORDS;
-    uint16_t* body0_g = p.body0 + (size_t)e * NS * 64;
-    uint16_t* ring_g = p.ring + (size_t)e * NS * cap;
+    uint32_t* hdr_g = hdr + (size_t)e * MSNAKE_HDR_WORDS;
+    uint16_t* body0_g = body0 + (size_t)e * NS * 64;
     uint32_t hv = hdr_g[lane];  // THE env record: lane l holds word l; lanes 32+f hold fruit f
     uint32_t cr[NS];            // cr[s], lane l: piece l of snake s (valid while l < len)
 #pragma unroll
     for (int s = 0; s < NS; ++s) cr[s] = body0_g[s * 64 + lane];
     int actv = 0;
-    if (MODE == 0 && lane < NS) actv = p.actions[(size_t)e * p.action_stride + lane];
+    if (MODE == 0 && lane < NS) actv = actions[(size_t)e * action_stride + lane];
 
-    uint8_t* obs_env = p.obs ? p.obs + (size_t)e * p.S : nullptr;
-    const uint32_t a = (uint32_t)((uintptr_t)obs_env & 15u);  // misalignment of this env's image
-    uint8_t* obs_al = obs_env - a;
-    const int nchunks = (int)((a + (uint32_t)p.S + 15u) >> 4);
-    if (p.obs) {
-        const uint4* tsrc = reinterpret_cast<const uint4*>(p.tmpl + (size_t)a * p.tmpl_stride);
+    // background image (black interior, white wall ring): one L1/L2-resident copy shared by every
+    // wave, padded so that no lane needs a predicate
+    if (obs) {
+        const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl);
         uint4* dst = reinterpret_cast<uint4*>(img);
-        for (int k0 = 0; k0 < nchunks; k0 += 256) {
+        for (int k0 = 0; k0 < (img_bytes >> 4); k0 += 256) {
+            const bool two = k0 + 128 < (img_bytes >> 4), four = k0 + 192 < (img_bytes >> 4);  // uniform
             uint4 t0, t1, t2, t3;
-            const int ka = k0 + lane, kb = ka + 64, kc = ka + 128, kd = ka + 192;
-            if (ka < nchunks) t0 = tsrc[ka];
-            if (kb < nchunks) t1 = tsrc[kb];
-            if (kc < nchunks) t2 = tsrc[kc];
-            if (kd < nchunks) t3 = tsrc[kd];
-            if (ka < nchunks) dst[ka] = t0;
-            if (kb < nchunks) dst[kb] = t1;
-            if (kc < nchunks) dst[kc] = t2;
-            if (kd < nchunks) dst[kd] = t3;
+            t0 = tsrc[k0 + lane];
+            if (k0 + 64 < (img_bytes >> 4)) t1 = tsrc[k0 + 64 + lane];
+            if (two) t2 = tsrc[k0 + 128 + lane];
+            if (four) t3 = tsrc[k0 + 192 + lane];
+            dst[k0 + lane] = t0;
+            if (k0 + 64 < (img_bytes >> 4)) dst[k0 + 64 + lane] = t1;
+            if (two) dst[k0 + 128 + lane] = t2;
+            if (four) dst[k0 + 192 + lane] = t3;
         }
     }
+    const int cap = p.cap;
+    uint16_t* ring_g = p.ring + (size_t)e * NS * cap;
 
     // ---- RNG: randint(n) = (u32 * n) >> 32 on draw number ctr (kept in the record) ---------------
     PhiloxBlock pb;
@@ -251,6 +264,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
         HV_SET(HDR_EP_LEN, 0u);
     }
 
+    DBG_EXIT(1)
     if (MODE == 0) {
         float reward = 0.0f;
         // ---- 1. sequential snake updates (order matters: a respawn sees earlier snakes moved,
@@ -282,7 +296,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
                 if (len >= g) len -= 1;             // [S]:134-135
             }
             len += 1;  // insert(0, head)
-            if (len > cap - 1) { len = cap - 1; if (lane == 0) atomicAdd(&p.stats[4], 1ull); }
+            if (len > cap - 1) { len = cap - 1; HV_SET(HDR_ACC_ERRORS, rdlane(hv, HDR_ACC_ERRORS) + 1u); }
             int hp = (int)(w0 & 0xFFFFu);
             hp = hp == 0 ? cap - 1 : hp - 1;
             HV_SET(b, (uint32_t)hp | ((uint32_t)len << 16));
@@ -308,6 +322,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
             }
         }
 
+        DBG_EXIT(2)
         // ---- 2. head-vs-piece matrix: bit (4*s + j) of `hits` = some piece of snake j other
         //         than s's own head lies on s's head -------------------------------------------
         uint32_t hd[NS], ln[NS], hp2[NS];
@@ -337,6 +352,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
             }
         }
 
+        DBG_EXIT(3)
         // ---- 3. aliveness, reward, done --------------------------------------------------------
         bool done;
         int num_alive;
@@ -383,6 +399,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
         }
         HV_SET(HDR_T, t);
 
+        DBG_EXIT(4)
         // ---- 4. vec layer: episode statistics and auto reset -----------------------------------
         float ep_ret = __uint_as_float(rdlane(hv, HDR_EP_RETURN)) + reward;
         uint32_t ep_len = rdlane(hv, HDR_EP_LEN) + 1;
@@ -390,12 +407,12 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
         uint32_t out_len = 0;
         if (done) {
             out_ret = ep_ret; out_len = ep_len;
-            if (lane == 0) {
-                atomicAdd(&p.stats[0], 1ull);
-                atomicAdd(&p.stats[1], (unsigned long long)ep_len);
-                atomicAdd(&p.stats[2], (unsigned long long)(long long)ep_ret);
-            }
-            if (p.auto_reset) {
+            // logging totals stay in the env record (summed by msnake_get_stats): same-address
+            // atomics from every finishing env would serialise at ~12 ns each
+            if (lane == HDR_ACC_EPISODES) hv += 1u;
+            if (lane == HDR_ACC_LEN) hv += ep_len;
+            if (lane == HDR_ACC_RETURN) hv += (uint32_t)(int)ep_ret;
+            if (auto_reset) {
                 ep_ret = 0.0f; ep_len = 0;
                 do_reset();
             }
@@ -413,6 +430,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
         }
     }
 
+    DBG_EXIT(5)
     // ---- 5. state write-back (fire and forget, overlaps the painting) ---------------------------
     if (MODE != 2) {
         hdr_g[lane] = hv;
@@ -421,9 +439,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
     }
 
     // ---- 6. paint the observation over the background, in reference order ----------------------
-    if (p.obs) {
+    if (obs) {
         wave_sync();
-        uint8_t* px = img + a;
+        uint8_t* px = img;
         // fruits first ([S]:43-44): red in every view; the background is already black
         if (lane >= 32 && lane < 32 + nf) {
             const uint32_t cell = hv & 0xFFFFu;
@@ -454,20 +472,43 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(const
             });
         }
         wave_sync();
-        // ---- 7. LDS image -> HBM: 16-byte aligned chunks, 1 KiB per wave instruction ----------
-        const uint32_t lo_b = a, hi_b = a + (uint32_t)p.S;
-        for (int k = lane; k < nchunks; k += 64) {
-            const uint32_t b0 = (uint32_t)k << 4;
-            if (b0 >= lo_b && b0 + 16u <= hi_b)
-                reinterpret_cast<uint4*>(obs_al)[k] = reinterpret_cast<const uint4*>(img)[k];
-        }
-        if (lane < 32) {  // the (at most two) chunks shared with the neighbouring envs: byte stores
-            const int kk = lane < 16 ? 0 : nchunks - 1;
-            const uint32_t b0 = (uint32_t)kk << 4, b = b0 + (uint32_t)(lane & 15);
-            const bool full = b0 >= lo_b && b0 + 16u <= hi_b;
-            if (!full && b >= lo_b && b < hi_b) obs_al[b] = img[b];
-        }
+        // ---- 7. LDS image -> HBM: 16 bytes per lane, 1 KiB contiguous per wave instruction.  The
+        //         3969-byte images are not 16-byte multiples, so the global side is byte-aligned
+        //         (the hardware splits the few lines that straddle); the last S%16 bytes go singly.
+        uint8_t* obs_env = obs + (size_t)e * S;
+        const int nfull = S >> 4;
+        for (int k = lane; k < nfull; k += 64)
+            *reinterpret_cast<uint4_unaligned*>(obs_env + 16 * k) = reinterpret_cast<const uint4*>(img)[k];
+        const int tail = (nfull << 4) + lane;
+        if (tail < S) obs_env[tail] = img[tail];
     }
+}
+
+// Sum the per-env logging totals into stats[0..4] (msnake_get_stats; off the step path).
+__global__ __launch_bounds__(256) void msnake_stats_kernel(uint32_t* __restrict__ hdr, int nenv,
+                                                           unsigned long long* __restrict__ stats, int clear) {
+    long long ep = 0, ln = 0, rt = 0, er = 0;
+    for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < nenv; e += (int)(gridDim.x * blockDim.x)) {
+        uint32_t* h = hdr + (size_t)e * MSNAKE_HDR_WORDS;
+        ep += h[HDR_ACC_EPISODES]; ln += h[HDR_ACC_LEN]; rt += (int)h[HDR_ACC_RETURN]; er += h[HDR_ACC_ERRORS];
+        if (clear) h[HDR_ACC_EPISODES] = h[HDR_ACC_LEN] = h[HDR_ACC_RETURN] = h[HDR_ACC_ERRORS] = 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ep += __shfl_down(ep, o); ln += __shfl_down(ln, o); rt += __shfl_down(rt, o); er += __shfl_down(er, o);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        atomicAdd(&stats[0], (unsigned long long)ep);
+        atomicAdd(&stats[1], (unsigned long long)ln);
+        atomicAdd(&stats[2], (unsigned long long)rt);
+        atomicAdd(&stats[4], (unsigned long long)er);
+    }
+}
+
+hipError_t launch_stats(uint32_t* hdr, int nenv, unsigned long long* stats, int clear, hipStream_t stream) {
+    const int blocks = nenv < 256 * 64 ? (nenv + 255) / 256 : 64;
+    hipLaunchKernelGGL(msnake_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, hdr, nenv, stats, clear);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -478,11 +519,19 @@ static hipError_t launch_ns(const StepParams& p, int mode, int epb, hipStream_t 
     const dim3 grid((unsigned)((p.nenv + epb - 1) / epb));
     const dim3 block(64u * (unsigned)epb);
     const size_t lds = (size_t)p.lds_per_wave * (size_t)epb;
+    static const uint32_t dbg_stage = getenv("MSNAKE_DBG_STAGE") ? (uint32_t)atoi(getenv("MSNAKE_DBG_STAGE")) : 0u;
+    const uint32_t pk0 = (uint32_t)p.dim | ((uint32_t)p.n_fruits << 8) | ((uint32_t)p.action_stride << 16) |
+                         ((uint32_t)(p.auto_reset ? 1 : 0) << 24) | (dbg_stage << 25);
+    const uint32_t pk1 = (uint32_t)p.S | ((uint32_t)p.lds_per_wave << 16);
+#define MSNAKE_LAUNCH(M)                                                                                  \
+    hipLaunchKernelGGL((msnake_step_kernel<RULES, NS, M>), grid, block, lds, stream, p.hdr, p.body0, p.obs, \
+                       p.tmpl, p.actions, p.nenv, pk0, pk1, p.rest)
     switch (mode) {
-        case 0: hipLaunchKernelGGL((msnake_step_kernel<RULES, NS, 0>), grid, block, lds, stream, p); break;
-        case 1: hipLaunchKernelGGL((msnake_step_kernel<RULES, NS, 1>), grid, block, lds, stream, p); break;
-        default: hipLaunchKernelGGL((msnake_step_kernel<RULES, NS, 2>), grid, block, lds, stream, p); break;
+        case 0: MSNAKE_LAUNCH(0); break;
+        case 1: MSNAKE_LAUNCH(1); break;
+        default: MSNAKE_LAUNCH(2); break;
     }
+#undef MSNAKE_LAUNCH
     return hipGetLastError();
 }
 
