@@ -49,7 +49,7 @@ def cpu_baseline(actions_host, seconds=12.0):
         ora.step(actions_host[k % len(actions_host)], threads=cores)
         k += 1
         el = time.perf_counter() - t0
-        if el >= seconds or k >= 4096:
+        if el >= seconds or k >= 200000:
             break
     return {"value": round(n * k / el, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{k} lockstep steps of {n} envs (19x19, 3 snakes, obs render included) in {el:.1f}s, "
@@ -57,10 +57,12 @@ def cpu_baseline(actions_host, seconds=12.0):
 
 
 def load_pmc_traffic():
-    """HBM bytes per launch from the committed PMC pass (profiles/hbm_traffic_r01.json), or None."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic_r01.json")
+    """HBM bytes per launch from the newest committed PMC pass (profiles/hbm_traffic_*.json:
+    separate FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH doubled for gfx950), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "hbm_traffic_*.json")))
     try:
-        with open(path) as f:
+        with open(files[-1]) as f:
             return json.load(f).get("hbm_bytes_per_launch")
     except Exception:  # noqa: BLE001
         return None

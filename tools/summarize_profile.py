@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_<tag>/ (tools/profile_round.sh) -> profiles/<tag>_*.  Keeps only summaries:
+the rocprofv3 --stats kernel table, per-kernel PMC medians, and hbm_traffic_<tag>.json which
+bench.py reads for roofline.traffic (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+gfx950, both counters in KiB)."""
+import collections
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(src, pattern), recursive=True)
+    return g[0] if g else None
+
+
+stats = one("kt/**/*kernel_stats.csv")
+if stats:
+    rows = list(csv.DictReader(open(stats)))
+    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        w.writerows(rows)
+    print("kernel stats:", [(r["Name"][:60], r["Calls"], r["AverageNs"]) for r in rows[:3]])
+
+pmc = {}
+for sub in ("pmc_fetch", "pmc_write", "pmc_insts", "pmc_cycles"):
+    f = one(f"{sub}/**/*counter_collection.csv")
+    if not f:
+        continue
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        if "msnake_step_kernel" not in k:
+            continue
+        for c, vals in v.items():
+            pmc.setdefault(k, {})[c] = {"n": len(vals), "median": statistics.median(vals), "mean": statistics.fmean(vals)}
+json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
+
+step = [k for k in pmc if ", 0>" in k]
+if step and "FETCH_SIZE" in pmc[step[0]] and "WRITE_SIZE" in pmc[step[0]]:
+    k = step[0]
+    fetch_kib, write_kib = pmc[k]["FETCH_SIZE"]["mean"], pmc[k]["WRITE_SIZE"]["mean"]
+    out = {"kernel": k, "fetch_size_kib_raw": fetch_kib, "write_size_kib": write_kib,
+           "fetch_correction": "x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B)",
+           "hbm_bytes_per_launch": int((2 * fetch_kib + write_kib) * 1024),
+           "launches": pmc[k]["WRITE_SIZE"]["n"]}
+    json.dump(out, open(os.path.join(dst, f"hbm_traffic_{tag}.json"), "w"), indent=1)
+    print(out)
+print(json.dumps({k[-40:]: {c: round(v["median"]) for c, v in d.items()} for k, d in pmc.items()}, indent=1))
