@@ -269,7 +269,7 @@ int msnake_get_state(msnake_handle h, int32_t env, int32_t* words, int32_t cap_w
     std::vector<uint16_t> ring((size_t)p.n_snakes * p.rest.cap);
     HIP_TRY(hipMemcpy(ring.data(), p.rest.ring + (size_t)env * p.n_snakes * p.rest.cap, ring.size() * 2, hipMemcpyDeviceToHost));
     int32_t need = 8 + 2 * p.n_fruits;
-    for (int s = 0; s < p.n_snakes; ++s) need += 6 + 2 * (int32_t)(hdr[HDR_SNAKE0 + 4 * s] >> 16);
+    for (int s = 0; s < p.n_snakes; ++s) need += 6 + 2 * (int32_t)(hdr[SN_A(s)] >> 16);
     if (!words || cap_words < need) return need;
     int32_t k = 0;
     words[k++] = (int32_t)hdr[HDR_T];
@@ -286,12 +286,12 @@ int msnake_get_state(msnake_handle h, int32_t env, int32_t* words, int32_t cap_w
         words[k++] = (int32_t)(c & 255u) - 1;
     }
     for (int s = 0; s < p.n_snakes; ++s) {
-        const uint32_t w0 = hdr[HDR_SNAKE0 + 4 * s], w2 = hdr[HDR_SNAKE0 + 4 * s + 2];
+        const uint32_t w0 = hdr[SN_A(s)], w2 = hdr[SN_C(s)];
         const int hp = (int)(w0 & 0xFFFFu), len = (int)(w0 >> 16), vel = (int)((w2 >> 16) & 7u);
         words[k++] = len;
         words[k++] = kVel0[vel];
         words[k++] = kVel1[vel];
-        words[k++] = (int32_t)hdr[HDR_SNAKE0 + 4 * s + 1];
+        words[k++] = (int32_t)hdr[SN_B(s)];
         const bool nw = h->cfg.rules == MSNAKE_RULES_NEW_WORLD;
         words[k++] = nw ? (int32_t)((hdr[HDR_FLAGS] >> s) & 1u) : 1;
         words[k++] = nw ? (int32_t)((hdr[HDR_FLAGS] >> (4 + s)) & 1u) : 0;
@@ -345,9 +345,9 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
             if (i < 64) body0[(size_t)s * 64 + i] = (uint16_t)c;
             if (i == 0) headc = c;
         }
-        hdr[HDR_SNAKE0 + 4 * s] = 0u | ((uint32_t)len << 16);
-        hdr[HDR_SNAKE0 + 4 * s + 1] = (uint32_t)grow;
-        hdr[HDR_SNAKE0 + 4 * s + 2] = headc | ((uint32_t)vel_code(v0, v1) << 16);
+        hdr[SN_A(s)] = 0u | ((uint32_t)len << 16);
+        hdr[SN_B(s)] = (uint32_t)grow;
+        hdr[SN_C(s)] = headc | ((uint32_t)vel_code(v0, v1) << 16);
         if (alive) flags |= 1u << s;
         if (in_dead) flags |= 16u << s;
     }

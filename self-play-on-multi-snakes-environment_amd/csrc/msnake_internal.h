@@ -15,15 +15,18 @@
 // (lane l <-> word l), plus 128 B per snake with its first 64 body cells in logical order.  Both
 // sit at addresses that depend only on the env index: one memory round trip per step.
 #define MSNAKE_HDR_WORDS 64
-#define HDR_T 0          // steps since reset ([S] state[4] / [NE] current_step)
-#define HDR_CTR_LO 1     // Philox draws consumed (64 bit)
-#define HDR_CTR_HI 2
-#define HDR_EP_RETURN 3  // Monitor: running episode return (f32 bits)
-#define HDR_EP_LEN 4     // Monitor: running episode length
-#define HDR_SPARE 5      // [A] spare_fruits
-#define HDR_NLIST 6      // [A] length of the fruit list
-#define HDR_FLAGS 7      // [N] bit s: Snake.alive, bit 4+s: snake in World.dead_snakes
-#define HDR_SNAKE0 8     // 4 words per snake: {ring head pos | len<<16, grow_to, head cell | vel<<16, -}
+// words 0..11: three 4-lane "columns" so that lane s of a DPP row shift holds snake s's field
+#define SN_A(s) (0 + (s))   // ring head pos | len << 16
+#define SN_B(s) (4 + (s))   // grow_to ([S] grow_to_lengths / [N] Snake.snake_length)
+#define SN_C(s) (8 + (s))   // head cell | velocity code << 16
+#define HDR_T 12         // steps since reset ([S] state[4] / [NE] current_step)
+#define HDR_CTR_LO 13    // Philox draws consumed (64 bit)
+#define HDR_CTR_HI 14
+#define HDR_FLAGS 15     // [N] bit s: Snake.alive, bit 4+s: snake in World.dead_snakes
+#define HDR_EP_RETURN 16 // Monitor: running episode return (f32 bits)
+#define HDR_EP_LEN 17    // Monitor: running episode length
+#define HDR_SPARE 18     // [A] spare_fruits
+#define HDR_NLIST 19     // [A] length of the fruit list
 #define HDR_ACC_EPISODES 24  // per-env totals since the last msnake_get_stats(reset=1): no hot-path atomics
 #define HDR_ACC_LEN 25
 #define HDR_ACC_RETURN 26    // int32, rewards are integral

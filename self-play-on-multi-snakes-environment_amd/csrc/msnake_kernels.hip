@@ -49,6 +49,16 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+// within each row of 16 lanes: lane l <- lane l+N (row_shl) / lane l-N (row_shr); lanes without a
+// source keep `old`
+template <int N>
+__device__ __forceinline__ uint32_t row_shl(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x100 + N, 0xF, 0xF, false);
+}
+template <int N>
+__device__ __forceinline__ uint32_t row_shr(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x110 + N, 0xF, 0xF, false);
+}
 // lane l <- lane l-1 (lane 0 keeps its value): v_mov_b32 dpp wave_shr:1
 __device__ __forceinline__ uint32_t shift_up1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false);
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         wave_sync();
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            const uint32_t w0 = rdlane(hv, HDR_SNAKE0 + 4 * j);
+            const uint32_t w0 = rdlane(hv, SN_A(j));
             for_each_piece(j, cr[j], (int)(w0 & 0xFFFFu), (int)(w0 >> 16), [&](int, uint32_t cell) {
                 // used = c1*dim + c0; out-of-grid heads alias onto other cells or fall outside
                 const int used = ((int)(cell & 255u) - 1) * dim + ((int)(cell >> 8) - 1);
@@ -231,15 +241,15 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     auto do_reset = [&]() {
         if (RULES == MSNAKE_RULES_NEW_WORLD) {  // bodies must be empty while the first ones are placed
 #pragma unroll
-            for (int s = 0; s < NS; ++s) HV_SET(HDR_SNAKE0 + 4 * s, 0u);
+            for (int s = 0; s < NS; ++s) HV_SET(SN_A(s), 0u);
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const uint32_t c0 = randint((uint32_t)dim), c1 = randint((uint32_t)dim);
             const uint32_t hd = ((c0 + 1) << 8) | (c1 + 1);
-            HV_SET(HDR_SNAKE0 + 4 * s, 1u << 16);   // head_pos 0, len 1
-            HV_SET(HDR_SNAKE0 + 4 * s + 1, 3u);     // grow_to 3
-            HV_SET(HDR_SNAKE0 + 4 * s + 2, hd);     // head cell, velocity (0,0)
+            HV_SET(SN_A(s), 1u << 16);   // head_pos 0, len 1
+            HV_SET(SN_B(s), 3u);     // grow_to 3
+            HV_SET(SN_C(s), hd);     // head cell, velocity (0,0)
             cr[s] = hd;
             if (lane == 0) ring_g[(size_t)s * cap] = (uint16_t)hd;
             if (RULES != MSNAKE_RULES_NEW_WORLD) {  // snake cell, then its fruit, unconstrained
@@ -267,25 +277,75 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     DBG_EXIT(1)
     if (MODE == 0) {
         float reward = 0.0f;
-        // ---- 1. sequential snake updates (order matters: a respawn sees earlier snakes moved,
-        //         a later snake can eat a fruit respawned this very step) -----------------------
+        // ---- 1. snake updates.  Fast path: all snakes at once on the VALU, lane s = snake s.
+        //         Valid whenever no moving snake eats (then no fruit respawns, so the updates do
+        //         not depend on each other); otherwise the sequential loop below runs instead.
+        constexpr int NF_STATIC = RULES == MSNAKE_RULES_NEW_WORLD ? -1 : NS;  // [S]: one fruit per snake
+        const uint32_t sA = hv, sB = row_shl<4>(0u, hv), sC = row_shl<8>(0u, hv);
+        const int v_len = (int)(sA >> 16), v_hp = (int)(sA & 0xFFFFu), v_grow = (int)sB;
+        const int v_head = (int)(sC & 0xFFFFu), v_vel = (int)((sC >> 16) & 7u);
+        // turn unless it is a 180-degree reversal: [S]:108-115 == [N]:34-41 == [A]:106-113
+        const int v_nvel = ((uint32_t)(actv - 1) < 4u && v_vel != ((actv + 1) & 3) + 1) ? actv : v_vel;
+        // snake_env moves only with a velocity ([S]:119); new_world always inserts a head, even a
+        // duplicate of itself ([N]:43-48,153)
+        const bool v_moves = lane < NS && v_len > 0 && (RULES == MSNAKE_RULES_NEW_WORLD || v_nvel != 0);
+        int v_d = (v_nvel & 1) ? 256 : 1;
+        v_d = v_nvel >= 3 ? -v_d : v_d;
+        v_d = v_nvel == 0 ? 0 : v_d;
+        const int v_nh = v_head + v_d;
+        uint32_t v_em = 0;  // bit f: fruit f lies on this snake's new head
+        if (NF_STATIC >= 0) {
+#pragma unroll
+            for (int f = 0; f < (NF_STATIC >= 0 ? NF_STATIC : 0); ++f)
+                v_em |= ((uint32_t)v_nh == (rdlane(hv, HDR_FRUIT0 + f) & 0xFFFFu)) ? (1u << f) : 0u;
+        } else {
+            for (int f = 0; f < nf; ++f)
+                v_em |= ((uint32_t)v_nh == (rdlane(hv, HDR_FRUIT0 + f) & 0xFFFFu)) ? (1u << f) : 0u;
+        }
+        const uint64_t mvmask = ballot(v_moves);
+        const bool any_eat = ballot(v_moves && v_em != 0) != 0;
+        if (!any_eat) {
+            int pops;
+            if (RULES == MSNAKE_RULES_NEW_WORLD) {  // [N]:143-150 runs the pop test once per fruit
+                pops = v_len - v_grow + 1;
+                pops = pops < 0 ? 0 : (pops > nf ? nf : pops);
+            } else {
+                pops = v_len >= v_grow ? 1 : 0;     // [S]:134-135
+            }
+            int nlen = v_len - pops + 1;            // insert(0, head)
+            if (ballot(v_moves && nlen > cap - 1) != 0) {  // unreachable under the documented caps
+                HV_SET(HDR_ACC_ERRORS, rdlane(hv, HDR_ACC_ERRORS) + 1u);
+                nlen = nlen > cap - 1 ? cap - 1 : nlen;
+            }
+            const int nhp = v_hp == 0 ? cap - 1 : v_hp - 1;
+            if (v_moves) ring_g[(size_t)lane * cap + nhp] = (uint16_t)v_nh;
+            const uint32_t nA = v_moves ? ((uint32_t)nhp | ((uint32_t)nlen << 16)) : sA;
+            const uint32_t nC = v_moves ? ((uint32_t)v_nh | ((uint32_t)v_nvel << 16)) : sC;
+            hv = lane < NS ? nA : hv;
+            const uint32_t nC8 = row_shr<8>(hv, nC);
+            hv = (lane >= 8 && lane < 8 + NS) ? nC8 : hv;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if ((mvmask >> s) & 1ull) {
+                    const uint32_t sh = shift_up1(cr[s]);
+                    cr[s] = lane == 0 ? rdlane((uint32_t)v_nh, s) : sh;
+                }
+        } else {
+        // ---- 1b. sequential snake updates (order matters: a respawn sees earlier snakes moved,
+        //          a later snake can eat a fruit respawned this very step) ----------------------
 #pragma nounroll
         for (int s = 0; s < NS; ++s) {  // a real loop: the slow path below exists once in the code
-            const int b = HDR_SNAKE0 + 4 * s;
-            const uint32_t w0 = rdlane(hv, b), w2 = rdlane(hv, b + 2);
+            const uint32_t w0 = rdlane(hv, SN_A(s)), w2 = rdlane(hv, SN_C(s));
             int len = (int)(w0 >> 16);
             if (len == 0) continue;
             const int vel = (int)((w2 >> 16) & 7u), head = (int)(w2 & 0xFFFFu);
             const int act = (int)rdlane((uint32_t)actv, s);
-            // turn unless it is a 180-degree reversal: [S]:108-115 == [N]:34-41 == [A]:106-113
             const int nvel = (act >= 1 && act <= 4 && vel != ((act + 1) & 3) + 1) ? act : vel;
-            // snake_env moves only with a velocity ([S]:119); new_world always inserts a head,
-            // even a duplicate of itself ([N]:43-48,153)
             if (RULES != MSNAKE_RULES_NEW_WORLD && nvel == 0) continue;
             const int nh = head + cell_step(nvel);
             // fruits equal to the new head, as a bit mask over fruit indices
             const uint64_t em = ballot(lane >= 32 && lane < 32 + nf && (hv & 0xFFFFu) == (uint32_t)nh) >> 32;
-            int g = (int)rdlane(hv, b + 1);
+            int g = (int)rdlane(hv, SN_B(s));
             if (RULES == MSNAKE_RULES_NEW_WORLD) {
                 for (int f = 0; f < nf; ++f) {  // [N]:143-150: the pop test sits inside the fruit loop
                     if ((em >> f) & 1ull) g += 2;
@@ -299,9 +359,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             if (len > cap - 1) { len = cap - 1; HV_SET(HDR_ACC_ERRORS, rdlane(hv, HDR_ACC_ERRORS) + 1u); }
             int hp = (int)(w0 & 0xFFFFu);
             hp = hp == 0 ? cap - 1 : hp - 1;
-            HV_SET(b, (uint32_t)hp | ((uint32_t)len << 16));
-            HV_SET(b + 1, (uint32_t)g);
-            HV_SET(b + 2, (uint32_t)nh | ((uint32_t)nvel << 16));
+            HV_SET(SN_A(s), (uint32_t)hp | ((uint32_t)len << 16));
+            HV_SET(SN_B(s), (uint32_t)g);
+            HV_SET(SN_C(s), (uint32_t)nh | ((uint32_t)nvel << 16));
             if (lane == 0) ring_g[(size_t)s * cap + hp] = (uint16_t)nh;
 #pragma unroll
             for (int j = 0; j < NS; ++j)
@@ -310,7 +370,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     cr[j] = lane == 0 ? (uint32_t)nh : sh;
                 }
             if (s == 0) reward = (float)__builtin_popcountll(em);
-            if (em != 0) {  // slow path: respawn each eaten fruit, in index order
+            if (em != 0) {  // respawn each eaten fruit, in index order
                 build_free();
                 uint64_t m = em;
                 while (m) {
@@ -321,43 +381,55 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 }
             }
         }
+        }
 
         DBG_EXIT(2)
-        // ---- 2. head-vs-piece matrix: bit (4*s + j) of `hits` = some piece of snake j other
-        //         than s's own head lies on s's head -------------------------------------------
+        // ---- 2. head-vs-piece matrix: some piece of snake j other than s's own head lies on
+        //         s's head.  [S] only needs "any j" per s; [N] needs the full matrix -------------
         uint32_t hd[NS], ln[NS], hp2[NS];
+        uint32_t maxlen = 0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const uint32_t w0 = rdlane(hv, HDR_SNAKE0 + 4 * s);
-            hd[s] = rdlane(hv, HDR_SNAKE0 + 4 * s + 2) & 0xFFFFu;
+            const uint32_t w0 = rdlane(hv, SN_A(s));
+            hd[s] = rdlane(hv, SN_C(s)) & 0xFFFFu;
             ln[s] = w0 >> 16; hp2[s] = w0 & 0xFFFFu;
+            maxlen = ln[s] > maxlen ? ln[s] : maxlen;
         }
-        uint32_t hitl = 0;  // per-lane accumulation
+        uint32_t hitl = 0;  // per-lane accumulation, bit (4*s + j)
 #pragma unroll
-        for (int j = 0; j < NS; ++j)
-            for_each_piece(j, cr[j], (int)hp2[j], (int)ln[j], [&](int i, uint32_t cell) {
+        for (int j = 0; j < NS; ++j) {
+            const bool valid = (uint32_t)lane < ln[j];
 #pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    if (cell == hd[s] && !(j == s && i == 0)) hitl |= 1u << (4 * s + j);
-            });
-        uint32_t hits = 0;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (RULES == MSNAKE_RULES_NEW_WORLD) {
-#pragma unroll
-                for (int j = 0; j < NS; ++j)
-                    if (ballot((hitl >> (4 * s + j)) & 1u) != 0) hits |= 1u << (4 * s + j);
-            } else {
-                if (ballot(((hitl >> (4 * s)) & 15u) != 0) != 0) hits |= 1u << (4 * s);
-            }
+            for (int s = 0; s < NS; ++s)
+                hitl |= (valid && cr[j] == hd[s] && !(j == s && lane == 0)) ? (1u << (4 * s + j)) : 0u;
         }
-
+        if (maxlen > 64) {  // bodies longer than one chunk: the rest comes from the ring
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+                for (int base = 64; base < (int)ln[j]; base += 64) {
+                    const int i = base + lane;
+                    if (i < (int)ln[j]) {
+                        int idx = (int)hp2[j] + i;
+                        idx = idx >= cap ? idx - cap : idx;
+                        const uint32_t cell = ring_g[(size_t)j * cap + idx];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s)
+                            hitl |= (cell == hd[s]) ? (1u << (4 * s + j)) : 0u;
+                    }
+                }
+        }
         DBG_EXIT(3)
         // ---- 3. aliveness, reward, done --------------------------------------------------------
         bool done;
         int num_alive;
-        uint32_t t = rdlane(hv, HDR_T) + 1;
+        const uint32_t t = rdlane(hv, HDR_T) + 1;
         if (RULES == MSNAKE_RULES_NEW_WORLD) {
+            uint32_t hits = 0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+                    if (ballot((hitl >> (4 * s + j)) & 1u) != 0) hits |= 1u << (4 * s + j);
             // [N]:101-107 + :111-132: in snake order, clearing bodies as it goes
             uint32_t flags = rdlane(hv, HDR_FLAGS);
             bool done0 = false;
@@ -374,7 +446,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     if (other) { ln[s] = 0; alive = false; }
                     else alive = !((hits >> (4 * s + s)) & 1u);  // self hit: not alive, body kept
                 }
-                if (ln[s] == 0) HV_SET(HDR_SNAKE0 + 4 * s, hp2[s]);
+                if (ln[s] == 0) HV_SET(SN_A(s), hp2[s]);
                 flags = alive ? (flags | (1u << s)) : (flags & ~(1u << s));
                 if (!alive) flags |= (16u << s);  // dead_snakes, append-once
                 if (s == 0) done0 = alive;        // [N]:107 (sic)
@@ -384,18 +456,19 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             done = (t >= (uint32_t)p.max_steps) || done0;
             num_alive = NS - __builtin_popcount((flags >> 4) & 15u);
         } else {
-            // [S]:178-197: simultaneous
-            int ndead = 0;
+            // [S]:147-164,178-197: simultaneous; lane s decides for snake s
+            uint32_t hitmask = 0;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const bool dead = ln[s] == 0 || !in_grid(hd[s], dim) || ((hits >> (4 * s)) & 1u);
-                ndead += dead;
-                if (dead) { ln[s] = 0; HV_SET(HDR_SNAKE0 + 4 * s, hp2[s]); }
-            }
-            const bool main_dead = ln[0] == 0;
+            for (int s = 0; s < NS; ++s)
+                if (ballot(((hitl >> (4 * s)) & 15u) != 0) != 0) hitmask |= 1u << s;
+            const uint32_t myhead = row_shl<8>(0u, hv) & 0xFFFFu;
+            const bool dead = lane < NS && ((hv >> 16) == 0 || !in_grid(myhead, dim) || ((hitmask >> lane) & 1u));
+            const uint32_t deadmask = (uint32_t)ballot(dead);
+            hv = dead ? (hv & 0xFFFFu) : hv;  // snakes[idx] = []
+            const bool main_dead = deadmask & 1u;
             if (main_dead) reward = -1.0f;
             done = (t >= (uint32_t)p.max_steps) || main_dead;
-            num_alive = NS - ndead;
+            num_alive = NS - __builtin_popcount(deadmask);
         }
         HV_SET(HDR_T, t);
 
@@ -455,7 +528,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         const uint32_t flags = rdlane(hv, HDR_FLAGS);
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            const uint32_t w0 = rdlane(hv, HDR_SNAKE0 + 4 * j);
+            const uint32_t w0 = rdlane(hv, SN_A(j));
             if (RULES == MSNAKE_RULES_NEW_WORLD && !((flags >> j) & 1u)) continue;  // [N]:219
             for_each_piece(j, cr[j], (int)(w0 & 0xFFFFu), (int)(w0 >> 16), [&](int i, uint32_t cell) {
                 if (!in_grid(cell, dim)) return;
