@@ -54,10 +54,7 @@ struct msnake_env {
     int epb;               // envs per workgroup
     hipStream_t last_stream;
     int64_t env_steps;
-    void* d_hdr;
-    void* d_body0;
-    void* d_ring;
-    void* d_tmpl;
+    void* d_state;
     void* d_stats;
 };
 
@@ -139,11 +136,10 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
     if (cfg->rules == MSNAKE_RULES_NEW_WORLD && cfg->max_steps + 2 > need) need = cfg->max_steps + 2;
     p.rest.cap = (need + 63) / 64 * 64;
     p.img_bytes = (p.S + 1023) / 1024 * 1024;  // whole 1 KiB wave-instructions, no lane predicates
-    p.rest.occ_bytes = (n2 + 15) / 16 * 16;
-    p.lds_per_wave = p.img_bytes + p.rest.occ_bytes;
     p.rest.seed_lo = (uint32_t)cfg->seed;
     p.rest.seed_hi = (uint32_t)(cfg->seed >> 32);
     p.rest.env_id_base = cfg->env_id_base;
+    p.lds_per_wave = p.img_bytes + (n2 + 15) / 16 * 16;  // composed image + respawn occupancy
     h->epb = MSNAKE_MAX_ENVS_PER_BLOCK;
     while (h->epb > 1 && (size_t)h->epb * p.lds_per_wave > 64 * 1024) h->epb >>= 1;
     if ((size_t)p.lds_per_wave > 64 * 1024 - 16 || p.S > 0xFFFF) {
@@ -152,36 +148,35 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
     }
 
     const size_t hdr_bytes = (size_t)p.nenv * MSNAKE_HDR_WORDS * 4;
-    const size_t ring_bytes = (size_t)p.nenv * p.n_snakes * p.rest.cap * 2;
     const size_t body0_bytes = (size_t)p.nenv * p.n_snakes * 64 * 2;
     const size_t tmpl_bytes = (size_t)p.img_bytes;
+    const size_t ring_bytes = (size_t)p.nenv * p.n_snakes * p.rest.cap * 2;
+    const size_t state_bytes = hdr_bytes + body0_bytes + tmpl_bytes + ring_bytes;
     hipError_t e;
-    if ((e = hipMalloc(&h->d_hdr, hdr_bytes)) != hipSuccess || (e = hipMalloc(&h->d_ring, ring_bytes)) != hipSuccess ||
-        (e = hipMalloc(&h->d_body0, body0_bytes)) != hipSuccess || (e = hipMemset(h->d_body0, 0, body0_bytes)) != hipSuccess ||
-        (e = hipMalloc(&h->d_tmpl, tmpl_bytes)) != hipSuccess || (e = hipMalloc(&h->d_stats, 64)) != hipSuccess ||
-        (e = hipMemset(h->d_hdr, 0, hdr_bytes)) != hipSuccess || (e = hipMemset(h->d_ring, 0, ring_bytes)) != hipSuccess ||
-        (e = hipMemset(h->d_stats, 0, 64)) != hipSuccess) {
-        (void)hipFree(h->d_hdr); (void)hipFree(h->d_body0); (void)hipFree(h->d_ring); (void)hipFree(h->d_tmpl); (void)hipFree(h->d_stats);
+    if ((e = hipMalloc(&h->d_state, state_bytes)) != hipSuccess || (e = hipMalloc(&h->d_stats, 64)) != hipSuccess ||
+        (e = hipMemset(h->d_state, 0, state_bytes)) != hipSuccess || (e = hipMemset(h->d_stats, 0, 64)) != hipSuccess) {
+        (void)hipFree(h->d_state); (void)hipFree(h->d_stats);
         free(h);
-        return fail(MSNAKE_E_HIP, "allocating %zu bytes of env state failed: %s", hdr_bytes + ring_bytes + tmpl_bytes,
-                    hipGetErrorString(e));
+        return fail(MSNAKE_E_HIP, "allocating %zu bytes of env state failed: %s", state_bytes, hipGetErrorString(e));
     }
+    p.state = static_cast<uint8_t*>(h->d_state);
+    p.hdr = reinterpret_cast<uint32_t*>(p.state);
+    p.body0 = reinterpret_cast<uint16_t*>(p.state + hdr_bytes);
+    p.tmpl = p.state + hdr_bytes + body0_bytes;
+    p.ring = reinterpret_cast<uint16_t*>(p.state + hdr_bytes + body0_bytes + tmpl_bytes);
+    p.stats = static_cast<unsigned long long*>(h->d_stats);
     // background image: black interior, white 1-px wall ring (snake_multiple_test.py:38,52-56)
     std::vector<uint8_t> tmpl(tmpl_bytes, 0);
     for (int r = 0; r < W; ++r)
         for (int c = 0; c < W; ++c)
             if (r == 0 || r == W - 1 || c == 0 || c == W - 1)
                 memset(&tmpl[((size_t)r * W + c) * p.C], 255, (size_t)p.C);
-    if ((e = hipMemcpy(h->d_tmpl, tmpl.data(), tmpl_bytes, hipMemcpyHostToDevice)) != hipSuccess) {
-        (void)hipFree(h->d_hdr); (void)hipFree(h->d_body0); (void)hipFree(h->d_ring); (void)hipFree(h->d_tmpl); (void)hipFree(h->d_stats);
+    if ((e = hipMemcpy(const_cast<uint8_t*>(p.tmpl), tmpl.data(), tmpl_bytes, hipMemcpyHostToDevice)) != hipSuccess) {
+        (void)hipFree(h->d_state); (void)hipFree(h->d_stats);
         free(h);
         return fail(MSNAKE_E_HIP, "uploading the background image failed: %s", hipGetErrorString(e));
     }
-    p.hdr = static_cast<uint32_t*>(h->d_hdr);
-    p.rest.ring = static_cast<uint16_t*>(h->d_ring);
-    p.body0 = static_cast<uint16_t*>(h->d_body0);
-    p.tmpl = static_cast<const uint8_t*>(h->d_tmpl);
-    p.rest.stats = static_cast<unsigned long long*>(h->d_stats);
+    if (const char* dbg = getenv("MSNAKE_DBG_STAGE")) p.rest.dbg_stage = (uint32_t)atoi(dbg);
     h->magic = kMagic;
     *out = h;
     return MSNAKE_OK;
@@ -191,7 +186,7 @@ int msnake_destroy(msnake_handle h) {
     if (int rc = check(h)) return rc;
     DeviceGuard guard(h->cfg.device);
     (void)hipDeviceSynchronize();
-    (void)hipFree(h->d_hdr); (void)hipFree(h->d_body0); (void)hipFree(h->d_ring); (void)hipFree(h->d_tmpl); (void)hipFree(h->d_stats);
+    (void)hipFree(h->d_state); (void)hipFree(h->d_stats);
     h->magic = 0;
     free(h);
     return MSNAKE_OK;
@@ -233,8 +228,8 @@ int msnake_step(msnake_handle h, const int32_t* actions_dev, int32_t action_stri
                 uint8_t* done_dev, msnake_info* info_dev, void* stream) {
     if (int rc = check(h)) return rc;
     if (!actions_dev || !rew_dev || !done_dev) return fail(MSNAKE_E_ARG, "msnake_step: actions/rew/done must not be NULL");
-    if (action_stride < h->p.n_snakes)
-        return fail(MSNAKE_E_ARG, "action_stride %d < n_snakes %d", action_stride, h->p.n_snakes);
+    if (action_stride < h->p.n_snakes || action_stride > 7)
+        return fail(MSNAKE_E_ARG, "action_stride %d must be in [n_snakes=%d, 7]", action_stride, h->p.n_snakes);
     if (((uintptr_t)actions_dev & 3) || ((uintptr_t)rew_dev & 3) || ((uintptr_t)info_dev & 15))
         return fail(MSNAKE_E_ALIGN, "actions/rew must be 4-byte and info 16-byte aligned");
     int rc = launch(h, 0, actions_dev, action_stride, obs_dev, rew_dev, done_dev, info_dev, stream);
@@ -267,7 +262,7 @@ int msnake_get_state(msnake_handle h, int32_t env, int32_t* words, int32_t cap_w
     uint32_t hdr[MSNAKE_HDR_WORDS];
     HIP_TRY(hipMemcpy(hdr, p.hdr + (size_t)env * MSNAKE_HDR_WORDS, sizeof(hdr), hipMemcpyDeviceToHost));
     std::vector<uint16_t> ring((size_t)p.n_snakes * p.rest.cap);
-    HIP_TRY(hipMemcpy(ring.data(), p.rest.ring + (size_t)env * p.n_snakes * p.rest.cap, ring.size() * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ring.data(), p.ring + (size_t)env * p.n_snakes * p.rest.cap, ring.size() * 2, hipMemcpyDeviceToHost));
     int32_t need = 8 + 2 * p.n_fruits;
     for (int s = 0; s < p.n_snakes; ++s) need += 6 + 2 * (int32_t)(hdr[SN_A(s)] >> 16);
     if (!words || cap_words < need) return need;
@@ -355,7 +350,7 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
     DeviceGuard guard(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(p.hdr + (size_t)env * MSNAKE_HDR_WORDS, hdr, sizeof(hdr), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(p.rest.ring + (size_t)env * p.n_snakes * p.rest.cap, ring.data(), ring.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p.ring + (size_t)env * p.n_snakes * p.rest.cap, ring.data(), ring.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p.body0 + (size_t)env * p.n_snakes * 64, body0.data(), body0.size() * 2, hipMemcpyHostToDevice));
     return MSNAKE_OK;
 }
@@ -366,7 +361,7 @@ int msnake_get_stats(msnake_handle h, msnake_stats* out, int32_t reset) {
     DeviceGuard guard(h->cfg.device);
     // the totals live in the env records; sum (and optionally clear) them behind the last step
     HIP_TRY(hipMemsetAsync(h->d_stats, 0, 64, h->last_stream));
-    HIP_TRY(msnake::launch_stats(h->p.hdr, h->p.nenv, h->p.rest.stats, reset ? 1 : 0, h->last_stream));
+    HIP_TRY(msnake::launch_stats(h->p.hdr, h->p.nenv, h->p.stats, reset ? 1 : 0, h->last_stream));
     unsigned long long raw[8];
     HIP_TRY(hipMemcpyAsync(raw, h->d_stats, sizeof(raw), hipMemcpyDeviceToHost, h->last_stream));
     HIP_TRY(hipStreamSynchronize(h->last_stream));

@@ -37,18 +37,16 @@
 
 namespace msnake {
 
-// rarely needed kernel arguments, passed by value behind the preloaded ones
+// kernel arguments that did not fit the 13 preloaded dwords, passed by value behind them
 struct StepRest {
-    uint16_t* ring;              // [nenv][n_snakes][cap] every body cell, piece i at (head_pos + i) % cap
-    unsigned long long* stats;   // [8]
-    float* rew;
+    msnake_info* info;           // per-call output (may be NULL)
+    float* rew;                  // (host copy; the kernel gets these two preloaded)
     uint8_t* done;
-    msnake_info* info;
     uint64_t env_id_base;
     uint32_t seed_lo, seed_hi;
     int32_t cap;                 // ring capacity in cells (multiple of 64)
     int32_t max_steps;
-    int32_t occ_bytes;
+    uint32_t dbg_stage;          // timing-only early exits (MSNAKE_DBG_STAGES builds)
     int32_t reserved;
 };
 
@@ -58,10 +56,14 @@ struct StepParams {
     int32_t lds_per_wave;  // bytes of LDS per env: padded image + occupancy bytes
     int32_t img_bytes;     // S rounded up to 1 KiB
     int32_t action_stride;
-    // state (HBM, owned by the handle)
-    uint32_t* hdr;               // [nenv][64]
-    uint16_t* body0;             // [nenv][n_snakes][64] the first 64 body cells in logical order
-    const uint8_t* tmpl;         // [img_bytes] background image
+    // state (HBM, owned by the handle): ONE allocation
+    //   [hdr: nenv x 256 B][body0: nenv x n_snakes x 128 B][tmpl: img_bytes][ring: nenv x n_snakes x cap x 2 B]
+    uint8_t* state;
+    uint32_t* hdr;               // views into `state` for the host-side paths
+    uint16_t* body0;
+    const uint8_t* tmpl;
+    uint16_t* ring;
+    unsigned long long* stats;   // [8], separate small allocation (msnake_get_stats)
     // per-call i/o (device pointers owned by the caller)
     const int32_t* actions;
     uint8_t* obs;

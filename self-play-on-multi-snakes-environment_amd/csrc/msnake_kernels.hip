@@ -65,16 +65,14 @@ __device__ __forceinline__ uint32_t shift_up1(uint32_t v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Philox4x32-10 on wave-uniform operands (rocRAND's seed / subsequence / offset convention):
-// draw i of global env g = word (i & 3) of philox(counter = {i>>2, g}, key = seed).
+// Philox4x32-10 (rocRAND's seed / subsequence / offset convention): draw i of global env g is word
+// (i & 3) of philox(counter = {i>>2, g}, key = seed).  Evaluated on the VALU with lane l computing
+// draw (base + l): one evaluation yields the next 64 draws of the env (a reset needs 12).
 // ------------------------------------------------------------------------------------------------
-struct PhiloxBlock {
-    uint32_t b0, b1, b2, b3, blk_lo, blk_hi;
-    bool valid;
-};
-
-__device__ __forceinline__ void philox_block(PhiloxBlock& r, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                             uint32_t k0, uint32_t k1) {
+__device__ __forceinline__ uint32_t philox_draws(uint32_t base_lo, uint32_t base_hi, int lane, uint32_t g_lo,
+                                                 uint32_t g_hi, uint32_t k0, uint32_t k1) {
+    const uint64_t d = (((uint64_t)base_hi << 32) | base_lo) + (uint64_t)lane;
+    uint32_t c0 = (uint32_t)(d >> 2), c1 = (uint32_t)(d >> 34), c2 = g_lo, c3 = g_hi;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
@@ -83,7 +81,8 @@ __device__ __forceinline__ void philox_block(PhiloxBlock& r, uint32_t c0, uint32
         c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    r.b0 = c0; r.b1 = c1; r.b2 = c2; r.b3 = c3;
+    const uint32_t sel = (uint32_t)d & 3u;
+    return sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -108,8 +107,8 @@ typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
 // without waiting for a scalar-memory round trip; the rarely used rest comes by value behind them.
 template <int RULES, int NS, int MODE>
 __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
-    uint32_t* __restrict__ hdr, uint16_t* __restrict__ body0, uint8_t* __restrict__ obs,
-    const uint8_t* __restrict__ tmpl, const int32_t* __restrict__ actions, const int32_t nenv, const uint32_t pk0,
+    uint8_t* __restrict__ state, uint8_t* __restrict__ obs, const int32_t* __restrict__ actions,
+    float* __restrict__ rew_out, uint8_t* __restrict__ done_out, const int32_t nenv, const uint32_t pk0,
     const uint32_t pk1, const StepRest p) {
     constexpr int VIEWS = RULES == MSNAKE_RULES_NEW_WORLD ? NS : 3;
     constexpr int C = 3 * VIEWS;
@@ -119,19 +118,30 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     const int e = (int)(blockIdx.x * (blockDim.x >> 6)) + wave;
     if (e >= nenv) return;
 
-    const int dim = (int)(pk0 & 255u), nf = (int)((pk0 >> 8) & 255u), action_stride = (int)((pk0 >> 16) & 255u);
-    const bool auto_reset = (pk0 >> 24) & 1u;
-    const uint32_t dbg = pk0 >> 25;  // timing-only early exits (MSNAKE_DBG_STAGE), 0 in production
-#define DBG_EXIT(n) if (dbg == (n)) { if (hv == 0xDEADBEEFu) hdr_g[lane] = hv + cr[0]; return; }
-    const int S = (int)(pk1 & 0xFFFFu), lds_per_wave = (int)(pk1 >> 16);
+    // pk0 = dim | n_fruits<<6 | action_stride<<12 | auto_reset<<15 | max_steps<<16 ; pk1 = S | cap<<16
+    const int dim = (int)(pk0 & 63u), nf = (int)((pk0 >> 6) & 63u), action_stride = (int)((pk0 >> 12) & 7u);
+    const bool auto_reset = (pk0 >> 15) & 1u;
+    const uint32_t max_steps = pk0 >> 16;
+    const int S = (int)(pk1 & 0xFFFFu), cap = (int)(pk1 >> 16);
     const int W = dim + 2, n2 = dim * dim;
     const int img_bytes = (S + 1023) & ~1023;  // image padded to whole 1 KiB wave-instructions
-    uint8_t* img = smem + (size_t)wave * lds_per_wave;
-    uint8_t* occ = img + img_bytes;
+    const int occ_bytes = (n2 + 15) & ~15;
+    uint8_t* img = smem + (size_t)wave * (size_t)(img_bytes + occ_bytes);  // observation being composed
+    uint8_t* occ = img + img_bytes;                                        // respawn occupancy
+#ifdef MSNAKE_DBG_STAGES
+    const uint32_t dbg = p.dbg_stage;  // timing-only early exits
+#define DBG_EXIT(n) if (dbg == (n)) { if (hv == 0xDEADBEEFu) hdr_g[lane] = hv + cr[0] + (uint32_t)actv; return; }
+#else
+#define DBG_EXIT(n)
+#endif
 
-    // ---- 0. every load whose address depends only on the env index -------------------------------
-    uint32_t* hdr_g = hdr + (size_t)e * MSNAKE_HDR_WORDS;
-    uint16_t* body0_g = body0 + (size_t)e * NS * 64;
+    // ---- 0. every load whose address depends only on the env index.  One allocation holds
+    //         [records | chunk-0 bodies | background image | rings]: one preloaded pointer ---------
+    uint32_t* hdr_g = reinterpret_cast<uint32_t*>(state) + (size_t)e * MSNAKE_HDR_WORDS;
+    uint16_t* body0_all = reinterpret_cast<uint16_t*>(state + (size_t)nenv * (MSNAKE_HDR_WORDS * 4));
+    uint16_t* body0_g = body0_all + (size_t)e * NS * 64;
+    const uint8_t* tmpl = reinterpret_cast<const uint8_t*>(body0_all + (size_t)nenv * NS * 64);
+    uint16_t* ring_g = reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl) + img_bytes) + (size_t)e * NS * cap;
     uint32_t hv = hdr_g[lane];  // THE env record: lane l holds word l; lanes 32+f hold fruit f
     uint32_t cr[NS];            // cr[s], lane l: piece l of snake s (valid while l < len)
 #pragma unroll
@@ -140,42 +150,37 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     if (MODE == 0 && lane < NS) actv = actions[(size_t)e * action_stride + lane];
 
     // background image (black interior, white wall ring): one L1/L2-resident copy shared by every
-    // wave, padded so that no lane needs a predicate
+    // wave, a whole number of 1 KiB wave-instructions so that no lane needs a predicate.
+    // (Storing the background to HBM right here, ahead of the logic, was measured and is SLOWER:
+    //  the 16 MB of early stores clog each CU's memory pipe in front of every later access.)
     if (obs) {
-        const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl);
-        uint4* dst = reinterpret_cast<uint4*>(img);
-        for (int k0 = 0; k0 < (img_bytes >> 4); k0 += 256) {
-            const bool two = k0 + 128 < (img_bytes >> 4), four = k0 + 192 < (img_bytes >> 4);  // uniform
-            uint4 t0, t1, t2, t3;
-            t0 = tsrc[k0 + lane];
-            if (k0 + 64 < (img_bytes >> 4)) t1 = tsrc[k0 + 64 + lane];
-            if (two) t2 = tsrc[k0 + 128 + lane];
-            if (four) t3 = tsrc[k0 + 192 + lane];
-            dst[k0 + lane] = t0;
-            if (k0 + 64 < (img_bytes >> 4)) dst[k0 + 64 + lane] = t1;
-            if (two) dst[k0 + 128 + lane] = t2;
-            if (four) dst[k0 + 192 + lane] = t3;
+        const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl) + lane;
+        uint4* dst = reinterpret_cast<uint4*>(img) + lane;
+        int k = 0;
+        const int nk = img_bytes >> 10;
+        for (; k + 4 <= nk; k += 4) {
+            const uint4 t0 = tsrc[(k + 0) * 64], t1 = tsrc[(k + 1) * 64], t2 = tsrc[(k + 2) * 64], t3 = tsrc[(k + 3) * 64];
+            dst[(k + 0) * 64] = t0; dst[(k + 1) * 64] = t1; dst[(k + 2) * 64] = t2; dst[(k + 3) * 64] = t3;
         }
+        for (; k < nk; ++k) dst[k * 64] = tsrc[k * 64];
     }
-    const int cap = p.cap;
-    uint16_t* ring_g = p.ring + (size_t)e * NS * cap;
 
-    // ---- RNG: randint(n) = (u32 * n) >> 32 on draw number ctr (kept in the record) ---------------
-    PhiloxBlock pb;
-    pb.valid = false; pb.b0 = pb.b1 = pb.b2 = pb.b3 = pb.blk_lo = pb.blk_hi = 0;
+    // ---- RNG: randint(n) = (u32 * n) >> 32 on draw number ctr (kept in the record).  Slow paths
+    //      only; `draws` caches the u32 of draws [draw_base, draw_base + 64) --------------------
+    uint32_t draws = 0, draw_base = 0;
+    bool draws_valid = false;
     auto randint = [&](uint32_t n) -> uint32_t {
         const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
-        const uint32_t blk_lo = (ctr_lo >> 2) | (ctr_hi << 30), blk_hi = ctr_hi >> 2;
-        if (!pb.valid || blk_lo != pb.blk_lo || blk_hi != pb.blk_hi) {
+        uint32_t idx = ctr_lo - draw_base;
+        if (!draws_valid || idx >= 64u) {
             const uint64_t gid = p.env_id_base + (uint64_t)e;
-            philox_block(pb, blk_lo, blk_hi, (uint32_t)gid, (uint32_t)(gid >> 32), p.seed_lo, p.seed_hi);
-            pb.blk_lo = blk_lo; pb.blk_hi = blk_hi; pb.valid = true;
+            draws = philox_draws(ctr_lo, ctr_hi, lane, (uint32_t)gid, (uint32_t)(gid >> 32), p.seed_lo, p.seed_hi);
+            draw_base = ctr_lo; draws_valid = true; idx = 0;
         }
-        const uint32_t sel = ctr_lo & 3u;
-        const uint32_t u = sel == 0 ? pb.b0 : sel == 1 ? pb.b1 : sel == 2 ? pb.b2 : pb.b3;
+        const uint32_t u = rdlane(draws, (int)idx);
         const uint32_t nlo = ctr_lo + 1;
         HV_SET(HDR_CTR_LO, nlo);
-        HV_SET(HDR_CTR_HI, ctr_hi + (nlo == 0));
+        if (nlo == 0) { HV_SET(HDR_CTR_HI, ctr_hi + 1); draws_valid = false; }
         return (uint32_t)(((uint64_t)u * n) >> 32);
     };
 
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     uint64_t freemask = 0;  // lane c: ballot of the free cells of index chunk c
     int nfree = 0;
     auto build_free = [&]() {
-        for (int i = lane * 4; i < p.occ_bytes; i += 256) *reinterpret_cast<uint32_t*>(occ + i) = 0u;
+        for (int i = lane * 4; i < occ_bytes; i += 256) *reinterpret_cast<uint32_t*>(occ + i) = 0u;
         wave_sync();
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             }
             HV_SET(HDR_FLAGS, flags);
             if (done0) reward = -1.0f;  // [NE]:39-40
-            done = (t >= (uint32_t)p.max_steps) || done0;
+            done = (t >= max_steps) || done0;
             num_alive = NS - __builtin_popcount((flags >> 4) & 15u);
         } else {
             // [S]:147-164,178-197: simultaneous; lane s decides for snake s
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             hv = dead ? (hv & 0xFFFFu) : hv;  // snakes[idx] = []
             const bool main_dead = deadmask & 1u;
             if (main_dead) reward = -1.0f;
-            done = (t >= (uint32_t)p.max_steps) || main_dead;
+            done = (t >= max_steps) || main_dead;
             num_alive = NS - __builtin_popcount(deadmask);
         }
         HV_SET(HDR_T, t);
@@ -493,8 +498,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         HV_SET(HDR_EP_RETURN, __float_as_uint(ep_ret));
         HV_SET(HDR_EP_LEN, ep_len);
         if (lane == 0) {
-            p.rew[e] = reward;
-            p.done[e] = done ? 1 : 0;
+            rew_out[e] = reward;
+            done_out[e] = done ? 1 : 0;
             if (p.info) {
                 int4 iv;
                 iv.x = (int)__float_as_uint(out_ret); iv.y = (int)out_len; iv.z = num_alive; iv.w = done ? 1 : 0;
@@ -524,7 +529,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 for (int v = 0; v < VIEWS; ++v) px[off + 3 * v] = 255;
             }
         }
-        // snakes in index order, head over body ([S]:46-50, draw_snake :24-33)
+        // snakes in index order, head over body ([S]:46-50, draw_snake :24-33); LDS writes of one
+        // wave execute in program order, which is what makes later painters win
         const uint32_t flags = rdlane(hv, HDR_FLAGS);
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -591,14 +597,13 @@ template <int RULES, int NS>
 static hipError_t launch_ns(const StepParams& p, int mode, int epb, hipStream_t stream) {
     const dim3 grid((unsigned)((p.nenv + epb - 1) / epb));
     const dim3 block(64u * (unsigned)epb);
+    const uint32_t pk0 = (uint32_t)p.dim | ((uint32_t)p.n_fruits << 6) | ((uint32_t)p.action_stride << 12) |
+                         ((uint32_t)(p.auto_reset ? 1 : 0) << 15) | ((uint32_t)p.rest.max_steps << 16);
+    const uint32_t pk1 = (uint32_t)p.S | ((uint32_t)p.rest.cap << 16);
     const size_t lds = (size_t)p.lds_per_wave * (size_t)epb;
-    static const uint32_t dbg_stage = getenv("MSNAKE_DBG_STAGE") ? (uint32_t)atoi(getenv("MSNAKE_DBG_STAGE")) : 0u;
-    const uint32_t pk0 = (uint32_t)p.dim | ((uint32_t)p.n_fruits << 8) | ((uint32_t)p.action_stride << 16) |
-                         ((uint32_t)(p.auto_reset ? 1 : 0) << 24) | (dbg_stage << 25);
-    const uint32_t pk1 = (uint32_t)p.S | ((uint32_t)p.lds_per_wave << 16);
 #define MSNAKE_LAUNCH(M)                                                                                  \
-    hipLaunchKernelGGL((msnake_step_kernel<RULES, NS, M>), grid, block, lds, stream, p.hdr, p.body0, p.obs, \
-                       p.tmpl, p.actions, p.nenv, pk0, pk1, p.rest)
+    hipLaunchKernelGGL((msnake_step_kernel<RULES, NS, M>), grid, block, lds, stream, p.state, p.obs, p.actions, \
+                       p.rest.rew, p.rest.done, p.nenv, pk0, pk1, p.rest)
     switch (mode) {
         case 0: MSNAKE_LAUNCH(0); break;
         case 1: MSNAKE_LAUNCH(1); break;
