@@ -90,8 +90,9 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
     if (cfg->num_envs < 1) return fail(MSNAKE_E_ARG, "num_envs must be >= 1 (got %d)", cfg->num_envs);
     if (cfg->dim < 2 || cfg->dim > MSNAKE_MAX_DIM)
         return fail(MSNAKE_E_ARG, "dim must be in [2, %d] (got %d)", MSNAKE_MAX_DIM, cfg->dim);
-    if (cfg->rules != MSNAKE_RULES_SNAKE_ENV && cfg->rules != MSNAKE_RULES_NEW_WORLD)
-        return fail(MSNAKE_E_ARG, "rules %d not supported by this build", cfg->rules);
+    if (cfg->rules != MSNAKE_RULES_SNAKE_ENV && cfg->rules != MSNAKE_RULES_NEW_WORLD &&
+        cfg->rules != MSNAKE_RULES_ADVERSARIAL)
+        return fail(MSNAKE_E_ARG, "rules %d is not one of MSNAKE_RULES_*", cfg->rules);
     if (cfg->rules == MSNAKE_RULES_NEW_WORLD) {
         if (cfg->n_snakes < 1 || cfg->n_snakes > MSNAKE_MAX_SNAKES)
             return fail(MSNAKE_E_ARG, "new_world: n_snakes must be in [1, %d]", MSNAKE_MAX_SNAKES);
@@ -151,7 +152,11 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
     const size_t body0_bytes = (size_t)p.nenv * p.n_snakes * 64 * 2;
     const size_t tmpl_bytes = (size_t)p.img_bytes;
     const size_t ring_bytes = (size_t)p.nenv * p.n_snakes * p.rest.cap * 2;
-    const size_t state_bytes = hdr_bytes + body0_bytes + tmpl_bytes + ring_bytes;
+    const bool adv = cfg->rules == MSNAKE_RULES_ADVERSARIAL;
+    p.fcap = (p.n_snakes + p.n_snakes * (n2 + 2) + 63) / 64 * 64;  // n fruits + every body of one episode
+    const size_t fl0_bytes = adv ? (size_t)p.nenv * 64 * 2 : 0;
+    const size_t flist_bytes = adv ? (size_t)p.nenv * p.fcap * 2 : 0;
+    const size_t state_bytes = hdr_bytes + body0_bytes + tmpl_bytes + ring_bytes + fl0_bytes + flist_bytes;
     hipError_t e;
     if ((e = hipMalloc(&h->d_state, state_bytes)) != hipSuccess || (e = hipMalloc(&h->d_stats, 64)) != hipSuccess ||
         (e = hipMemset(h->d_state, 0, state_bytes)) != hipSuccess || (e = hipMemset(h->d_stats, 0, 64)) != hipSuccess) {
@@ -164,6 +169,8 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
     p.body0 = reinterpret_cast<uint16_t*>(p.state + hdr_bytes);
     p.tmpl = p.state + hdr_bytes + body0_bytes;
     p.ring = reinterpret_cast<uint16_t*>(p.state + hdr_bytes + body0_bytes + tmpl_bytes);
+    p.fl0 = reinterpret_cast<uint16_t*>(p.state + hdr_bytes + body0_bytes + tmpl_bytes + ring_bytes);
+    p.flist = reinterpret_cast<uint16_t*>(p.state + hdr_bytes + body0_bytes + tmpl_bytes + ring_bytes + fl0_bytes);
     p.stats = static_cast<unsigned long long*>(h->d_stats);
     // background image: black interior, white 1-px wall ring (snake_multiple_test.py:38,52-56)
     std::vector<uint8_t> tmpl(tmpl_bytes, 0);
@@ -263,7 +270,14 @@ int msnake_get_state(msnake_handle h, int32_t env, int32_t* words, int32_t cap_w
     HIP_TRY(hipMemcpy(hdr, p.hdr + (size_t)env * MSNAKE_HDR_WORDS, sizeof(hdr), hipMemcpyDeviceToHost));
     std::vector<uint16_t> ring((size_t)p.n_snakes * p.rest.cap);
     HIP_TRY(hipMemcpy(ring.data(), p.ring + (size_t)env * p.n_snakes * p.rest.cap, ring.size() * 2, hipMemcpyDeviceToHost));
-    int32_t need = 8 + 2 * p.n_fruits;
+    const bool adv = h->cfg.rules == MSNAKE_RULES_ADVERSARIAL;
+    const int nfr = adv ? (int)hdr[HDR_NLIST] : p.n_fruits;
+    std::vector<uint16_t> flist;
+    if (adv) {
+        flist.resize((size_t)p.fcap);
+        HIP_TRY(hipMemcpy(flist.data(), p.flist + (size_t)env * p.fcap, flist.size() * 2, hipMemcpyDeviceToHost));
+    }
+    int32_t need = 8 + 2 * nfr;
     for (int s = 0; s < p.n_snakes; ++s) need += 6 + 2 * (int32_t)(hdr[SN_A(s)] >> 16);
     if (!words || cap_words < need) return need;
     int32_t k = 0;
@@ -273,10 +287,10 @@ int msnake_get_state(msnake_handle h, int32_t env, int32_t* words, int32_t cap_w
     words[k++] = (int32_t)hdr[HDR_SPARE];
     words[k++] = (int32_t)hdr[HDR_EP_LEN];
     words[k++] = (int32_t)hdr[HDR_EP_RETURN];
-    words[k++] = p.n_fruits;
+    words[k++] = nfr;
     words[k++] = p.n_snakes;
-    for (int f = 0; f < p.n_fruits; ++f) {
-        const uint32_t c = hdr[HDR_FRUIT0 + f] & 0xFFFFu;
+    for (int f = 0; f < nfr; ++f) {
+        const uint32_t c = adv ? (uint32_t)flist[(size_t)f] : (hdr[HDR_FRUIT0 + f] & 0xFFFFu);
         words[k++] = (int32_t)(c >> 8) - 1;
         words[k++] = (int32_t)(c & 255u) - 1;
     }
@@ -305,7 +319,11 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
     const msnake::StepParams& p = h->p;
     if (!words || n < 8) return fail(MSNAKE_E_STATE, "state buffer too short");
     if (words[7] != p.n_snakes) return fail(MSNAKE_E_STATE, "state has %d snakes, handle has %d", words[7], p.n_snakes);
-    if (words[6] != p.n_fruits) return fail(MSNAKE_E_STATE, "state has %d fruits, handle has %d", words[6], p.n_fruits);
+    const bool adv = h->cfg.rules == MSNAKE_RULES_ADVERSARIAL;
+    const int nfr = words[6];
+    if (!adv && nfr != p.n_fruits) return fail(MSNAKE_E_STATE, "state has %d fruits, handle has %d", nfr, p.n_fruits);
+    if (adv && (nfr < 0 || nfr > p.fcap)) return fail(MSNAKE_E_STATE, "fruit list of %d entries exceeds %d", nfr, p.fcap);
+    std::vector<uint16_t> flist(adv ? (size_t)p.fcap : 0, 0), fl0(adv ? 64 : 0, 0);
     uint32_t hdr[MSNAKE_HDR_WORDS] = {0};
     std::vector<uint16_t> ring((size_t)p.n_snakes * p.rest.cap, 0);
     std::vector<uint16_t> body0((size_t)p.n_snakes * 64, 0);
@@ -322,9 +340,18 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
     hdr[HDR_EP_LEN] = (uint32_t)words[k++];
     hdr[HDR_EP_RETURN] = (uint32_t)words[k++];
     k += 2;
-    if (n < k + 2 * p.n_fruits) return fail(MSNAKE_E_STATE, "state buffer truncated in fruits");
-    for (int f = 0; f < p.n_fruits; ++f, k += 2)
-        if (!cell(words[k], words[k + 1], &hdr[HDR_FRUIT0 + f])) return fail(MSNAKE_E_STATE, "fruit %d outside [-1, dim]", f);
+    if (n < k + 2 * nfr) return fail(MSNAKE_E_STATE, "state buffer truncated in fruits");
+    for (int f = 0; f < nfr; ++f, k += 2) {
+        uint32_t c;
+        if (!cell(words[k], words[k + 1], &c)) return fail(MSNAKE_E_STATE, "fruit %d outside [-1, dim]", f);
+        if (adv) {
+            flist[(size_t)f] = (uint16_t)c;
+            if (f < 64) fl0[(size_t)f] = (uint16_t)c;
+        } else {
+            hdr[HDR_FRUIT0 + f] = c;
+        }
+    }
+    if (adv) hdr[HDR_NLIST] = (uint32_t)nfr;
     uint32_t flags = 0;
     for (int s = 0; s < p.n_snakes; ++s) {
         if (n < k + 6) return fail(MSNAKE_E_STATE, "state buffer truncated in snake %d", s);
@@ -352,6 +379,10 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
     HIP_TRY(hipMemcpy(p.hdr + (size_t)env * MSNAKE_HDR_WORDS, hdr, sizeof(hdr), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p.ring + (size_t)env * p.n_snakes * p.rest.cap, ring.data(), ring.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p.body0 + (size_t)env * p.n_snakes * 64, body0.data(), body0.size() * 2, hipMemcpyHostToDevice));
+    if (adv) {
+        HIP_TRY(hipMemcpy(p.flist + (size_t)env * p.fcap, flist.data(), flist.size() * 2, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p.fl0 + (size_t)env * 64, fl0.data(), fl0.size() * 2, hipMemcpyHostToDevice));
+    }
     return MSNAKE_OK;
 }
 

@@ -58,11 +58,15 @@ struct StepParams {
     int32_t action_stride;
     // state (HBM, owned by the handle): ONE allocation
     //   [hdr: nenv x 256 B][body0: nenv x n_snakes x 128 B][tmpl: img_bytes][ring: nenv x n_snakes x cap x 2 B]
+    //   adversarial only: [fl0: nenv x 128 B][flist: nenv x fcap x 2 B] (fruit list chunk 0 / complete)
     uint8_t* state;
     uint32_t* hdr;               // views into `state` for the host-side paths
     uint16_t* body0;
     const uint8_t* tmpl;
     uint16_t* ring;
+    uint16_t* fl0;               // adversarial: first 64 fruit-list entries per env
+    uint16_t* flist;             // adversarial: complete fruit list per env, fcap entries
+    int32_t fcap;
     unsigned long long* stats;   // [8], separate small allocation (msnake_get_stats)
     // per-call i/o (device pointers owned by the caller)
     const int32_t* actions;

@@ -148,6 +148,18 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     for (int s = 0; s < NS; ++s) cr[s] = body0_g[s * 64 + lane];
     int actv = 0;
     if (MODE == 0 && lane < NS) actv = actions[(size_t)e * action_stride + lane];
+    // adversarial rules keep a growing fruit LIST ([A]:183-185 appends dead bodies to it): entries
+    // 0..63 in a VGPR like a body chunk (lane l = entry l), the complete list in HBM behind the rings
+    const int fcap = (NS + NS * (n2 + 2) + 63) & ~63;
+    uint16_t* fl0_g = nullptr;
+    uint16_t* flist_g = nullptr;
+    uint32_t fr = 0;
+    if (RULES == MSNAKE_RULES_ADVERSARIAL) {
+        uint16_t* fl0_all = reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl) + img_bytes) + (size_t)nenv * NS * cap;
+        fl0_g = fl0_all + (size_t)e * 64;
+        flist_g = fl0_all + (size_t)nenv * 64 + (size_t)e * fcap;
+        fr = fl0_g[lane];
+    }
 
     // background image (black interior, white wall ring): one L1/L2-resident copy shared by every
     // wave, a whole number of 1 KiB wave-instructions so that no lane needs a predicate.
@@ -196,6 +208,28 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 f(i, (uint32_t)ring_g[(size_t)s * cap + idx]);
             }
         }
+    };
+
+    // [A] fruit-list visitor: f(i, cell) for every list entry i < nlist
+    auto for_each_fruit = [&](int nlist, auto&& f) {
+        if (lane < nlist) f(lane, fr);
+        for (int base = 64; base < nlist; base += 64) {
+            const int i = base + lane;
+            if (i < nlist) f(i, (uint32_t)flist_g[i]);
+        }
+    };
+    // fruits (of any rule set) lying on `cell`: how many, wave-uniform
+    auto fruits_on = [&](uint32_t cell) -> int {
+        if (RULES == MSNAKE_RULES_ADVERSARIAL) {
+            const int nlist = (int)rdlane(hv, HDR_NLIST);
+            int n = __builtin_popcountll(ballot(lane < nlist && fr == cell));
+            for (int base = 64; base < nlist; base += 64) {
+                const int i = base + lane;
+                n += __builtin_popcountll(ballot(i < nlist && (uint32_t)flist_g[i < nlist ? i : 0] == cell));
+            }
+            return n;
+        }
+        return __builtin_popcountll(ballot(lane >= 32 && lane < 32 + nf && (hv & 0xFFFFu) == cell));
     };
 
     // ---- fruit respawn: [S]:202-217 safe_choose_cell == [N]:235-247 get_safe_cell --------------
@@ -259,7 +293,12 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             if (lane == 0) ring_g[(size_t)s * cap] = (uint16_t)hd;
             if (RULES != MSNAKE_RULES_NEW_WORLD) {  // snake cell, then its fruit, unconstrained
                 const uint32_t f0 = randint((uint32_t)dim), f1 = randint((uint32_t)dim);
-                HV_SET(HDR_FRUIT0 + s, ((f0 + 1) << 8) | (f1 + 1));
+                const uint32_t fc = ((f0 + 1) << 8) | (f1 + 1);
+                if (RULES == MSNAKE_RULES_ADVERSARIAL) {  // fruits = [] then append ([A]:224-229)
+                    if (lane == s) { fr = fc; flist_g[s] = (uint16_t)fc; }
+                } else {
+                    HV_SET(HDR_FRUIT0 + s, fc);
+                }
             }
         }
         if (RULES == MSNAKE_RULES_NEW_WORLD) {  // all snakes first, then n_fruits safe cells
@@ -269,6 +308,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 HV_SET(HDR_FRUIT0 + f, c);
             }
         }
+        if (RULES == MSNAKE_RULES_ADVERSARIAL) HV_SET(HDR_NLIST, (uint32_t)NS);  // spare_fruits survives ([A]:14)
         HV_SET(HDR_T, 0u);
         HV_SET(HDR_FLAGS, (1u << NS) - 1u);  // alive bits set, dead_snakes empty
     };
@@ -299,7 +339,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         v_d = v_nvel == 0 ? 0 : v_d;
         const int v_nh = v_head + v_d;
         uint32_t v_em = 0;  // bit f: fruit f lies on this snake's new head
-        if (NF_STATIC >= 0) {
+        if (RULES == MSNAKE_RULES_ADVERSARIAL) {
+            // list based, handled below
+        } else if (NF_STATIC >= 0) {
 #pragma unroll
             for (int f = 0; f < (NF_STATIC >= 0 ? NF_STATIC : 0); ++f)
                 v_em |= ((uint32_t)v_nh == (rdlane(hv, HDR_FRUIT0 + f) & 0xFFFFu)) ? (1u << f) : 0u;
@@ -308,7 +350,12 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 v_em |= ((uint32_t)v_nh == (rdlane(hv, HDR_FRUIT0 + f) & 0xFFFFu)) ? (1u << f) : 0u;
         }
         const uint64_t mvmask = ballot(v_moves);
-        const bool any_eat = ballot(v_moves && v_em != 0) != 0;
+        bool any_eat = ballot(v_moves && v_em != 0) != 0;
+        if (RULES == MSNAKE_RULES_ADVERSARIAL) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if (((mvmask >> s) & 1ull) && fruits_on(rdlane((uint32_t)v_nh, s)) != 0) any_eat = true;
+        }
         if (!any_eat) {
             int pops;
             if (RULES == MSNAKE_RULES_NEW_WORLD) {  // [N]:143-150 runs the pop test once per fruit
@@ -348,8 +395,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             const int nvel = (act >= 1 && act <= 4 && vel != ((act + 1) & 3) + 1) ? act : vel;
             if (RULES != MSNAKE_RULES_NEW_WORLD && nvel == 0) continue;
             const int nh = head + cell_step(nvel);
-            // fruits equal to the new head, as a bit mask over fruit indices
-            const uint64_t em = ballot(lane >= 32 && lane < 32 + nf && (hv & 0xFFFFu) == (uint32_t)nh) >> 32;
+            // fruits equal to the new head, as a bit mask over fruit indices (list rules: a count)
+            const uint64_t em = RULES == MSNAKE_RULES_ADVERSARIAL ? 0ull :
+                ballot(lane >= 32 && lane < 32 + nf && (hv & 0xFFFFu) == (uint32_t)nh) >> 32;
+            const int neat = RULES == MSNAKE_RULES_ADVERSARIAL ? fruits_on((uint32_t)nh) : __builtin_popcountll(em);
             int g = (int)rdlane(hv, SN_B(s));
             if (RULES == MSNAKE_RULES_NEW_WORLD) {
                 for (int f = 0; f < nf; ++f) {  // [N]:143-150: the pop test sits inside the fruit loop
@@ -357,8 +406,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     if (len >= g) len -= 1;
                 }
             } else {
-                g += 2 * __builtin_popcountll(em);  // [S]:126-132
-                if (len >= g) len -= 1;             // [S]:134-135
+                g += 2 * neat;           // [S]:126-132
+                if (len >= g) len -= 1;  // [S]:134-135
             }
             len += 1;  // insert(0, head)
             if (len > cap - 1) { len = cap - 1; HV_SET(HDR_ACC_ERRORS, rdlane(hv, HDR_ACC_ERRORS) + 1u); }
@@ -374,15 +423,37 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     const uint32_t sh = shift_up1(cr[j]);
                     cr[j] = lane == 0 ? (uint32_t)nh : sh;
                 }
-            if (s == 0) reward = (float)__builtin_popcountll(em);
-            if (em != 0) {  // respawn each eaten fruit, in index order
-                build_free();
-                uint64_t m = em;
-                while (m) {
-                    const int f = __builtin_ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const uint32_t c = safe_cell();
-                    HV_SET(HDR_FRUIT0 + f, c);
+            if (s == 0) reward = (float)neat;
+            if (neat != 0) {  // respawn each eaten fruit, in index order
+                if (RULES == MSNAKE_RULES_ADVERSARIAL) {
+                    // [A]:137-141: while spare_fruits > 0 an eaten fruit stays where it is
+                    int spare = (int)rdlane(hv, HDR_SPARE);
+                    const int nlist = (int)rdlane(hv, HDR_NLIST);
+                    bool built = false;
+                    for (int base = 0; base < nlist; base += 64) {
+                        const int i = base + lane;
+                        const uint32_t c = base == 0 ? fr : (uint32_t)flist_g[i < nlist ? i : 0];
+                        uint64_t m = ballot(i < nlist && c == (uint32_t)nh);
+                        while (m) {
+                            const int bit = __builtin_ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            if (spare > 0) { spare -= 1; continue; }
+                            if (!built) { build_free(); built = true; }
+                            const uint32_t nc = safe_cell();
+                            if (base == 0 && lane == bit) fr = nc;
+                            if (lane == 0) flist_g[base + bit] = (uint16_t)nc;
+                        }
+                    }
+                    HV_SET(HDR_SPARE, (uint32_t)spare);
+                } else {
+                    build_free();
+                    uint64_t m = em;
+                    while (m) {
+                        const int f = __builtin_ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const uint32_t c = safe_cell();
+                        HV_SET(HDR_FRUIT0 + f, c);
+                    }
                 }
             }
         }
@@ -469,6 +540,26 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             const uint32_t myhead = row_shl<8>(0u, hv) & 0xFFFFu;
             const bool dead = lane < NS && ((hv >> 16) == 0 || !in_grid(myhead, dim) || ((hitmask >> lane) & 1u));
             const uint32_t deadmask = (uint32_t)ballot(dead);
+            if (RULES == MSNAKE_RULES_ADVERSARIAL && deadmask != 0) {
+                // [A]:183-186: every piece of a snake that dies this step (its out-of-grid head
+                // included) joins the fruit list, and spare_fruits grows by len per piece
+                int nlist = (int)rdlane(hv, HDR_NLIST), spare = (int)rdlane(hv, HDR_SPARE);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int len_s = (int)ln[s];
+                    if (((deadmask >> s) & 1u) && len_s > 0) {
+                        const uint32_t moved = (uint32_t)__shfl((int)cr[s], lane - nlist);
+                        if (lane >= nlist && lane < nlist + len_s) fr = moved;
+                        for_each_piece(s, cr[s], (int)hp2[s], len_s, [&](int i, uint32_t cell) {
+                            flist_g[nlist + i] = (uint16_t)cell;
+                        });
+                        nlist += len_s;
+                        spare += len_s * len_s;
+                    }
+                }
+                HV_SET(HDR_NLIST, (uint32_t)nlist);
+                HV_SET(HDR_SPARE, (uint32_t)spare);
+            }
             hv = dead ? (hv & 0xFFFFu) : hv;  // snakes[idx] = []
             const bool main_dead = deadmask & 1u;
             if (main_dead) reward = -1.0f;
@@ -514,6 +605,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         hdr_g[lane] = hv;
 #pragma unroll
         for (int s = 0; s < NS; ++s) body0_g[s * 64 + lane] = (uint16_t)cr[s];
+        if (RULES == MSNAKE_RULES_ADVERSARIAL) fl0_g[lane] = (uint16_t)fr;
     }
 
     // ---- 6. paint the observation over the background, in reference order ----------------------
@@ -521,7 +613,16 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         wave_sync();
         uint8_t* px = img;
         // fruits first ([S]:43-44): red in every view; the background is already black
-        if (lane >= 32 && lane < 32 + nf) {
+        if (RULES == MSNAKE_RULES_ADVERSARIAL) {
+            // list entries outside the grid (dead out-of-grid heads) would land on the wall ring,
+            // which the reference paints last: skip them
+            for_each_fruit((int)rdlane(hv, HDR_NLIST), [&](int, uint32_t cell) {
+                if (!in_grid(cell, dim)) return;
+                const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * C;
+#pragma unroll
+                for (int v = 0; v < VIEWS; ++v) px[off + 3 * v] = 255;
+            });
+        } else if (lane >= 32 && lane < 32 + nf) {
             const uint32_t cell = hv & 0xFFFFu;
             if (in_grid(cell, dim)) {
                 const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * C;
@@ -631,6 +732,7 @@ hipError_t launch_step(const StepParams& p, int rules, int mode, int epb, hipStr
     switch (rules) {
         case MSNAKE_RULES_SNAKE_ENV: return launch_rules<MSNAKE_RULES_SNAKE_ENV>(p, mode, epb, stream);
         case MSNAKE_RULES_NEW_WORLD: return launch_rules<MSNAKE_RULES_NEW_WORLD>(p, mode, epb, stream);
+        case MSNAKE_RULES_ADVERSARIAL: return launch_rules<MSNAKE_RULES_ADVERSARIAL>(p, mode, epb, stream);
         default: return hipErrorInvalidValue;
     }
 }

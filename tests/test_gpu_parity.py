@@ -8,7 +8,7 @@ from golden_util import blob_to_obs, crc_rows, edge_cases, load_tape, state_view
 
 pytestmark = pytest.mark.gpu
 
-SUPPORTED_RULES = (0, 1)
+SUPPORTED_RULES = (0, 1, 2)
 
 
 def _mk(**kw):
@@ -122,6 +122,12 @@ def test_config3_4096_envs_19x19_3snakes():
 
 def test_config5_shape_19x19_2snakes_long_lived():
     _run_vs_oracle(2048, 19, 2, 2, "snake_env", 300, seed=4, greedy=0.7)
+
+
+def test_adversarial_vs_oracle():
+    _run_vs_oracle(4096, 10, 2, 2, "adversarial", 200, seed=6)
+    _run_vs_oracle(1024, 10, 3, 3, "adversarial", 300, seed=7, greedy=0.6)
+    _run_vs_oracle(512, 19, 3, 3, "adversarial", 200, seed=8)
 
 
 def test_new_world_4096_envs():
