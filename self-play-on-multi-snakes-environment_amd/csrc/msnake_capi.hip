@@ -108,7 +108,8 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
     }
     if (cfg->max_steps < 1 || cfg->max_steps > 60000)
         return fail(MSNAKE_E_ARG, "max_steps must be in [1, 60000]");
-    if (cfg->obs_scale != 1) return fail(MSNAKE_E_ARG, "obs_scale %d not supported by this build", cfg->obs_scale);
+    if (cfg->obs_scale != 1 && cfg->obs_scale != 4 && cfg->obs_scale != 7)
+        return fail(MSNAKE_E_ARG, "obs_scale must be 1, 4 (21->84) or 7 (12->84), got %d", cfg->obs_scale);
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -129,6 +130,7 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
     p.views = cfg->rules == MSNAKE_RULES_NEW_WORLD ? cfg->n_snakes : 3;
     p.C = 3 * p.views;
     p.S = W * W * p.C;
+    p.obs_scale = cfg->obs_scale;
     p.rest.max_steps = cfg->max_steps;
     p.auto_reset = cfg->auto_reset ? 1 : 0;
     // ring capacity: snake_env bodies hold distinct in-grid cells plus one transient head;
@@ -136,7 +138,12 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
     int need = n2 + 2;
     if (cfg->rules == MSNAKE_RULES_NEW_WORLD && cfg->max_steps + 2 > need) need = cfg->max_steps + 2;
     p.rest.cap = (need + 63) / 64 * 64;
-    p.img_bytes = (p.S + 1023) / 1024 * 1024;  // whole 1 KiB wave-instructions, no lane predicates
+    const int K = cfg->obs_scale;
+    if (K > 1 && (W * K * p.C) % 4 != 0) {
+        free(h);
+        return fail(MSNAKE_E_ARG, "obs_scale %d: output rows must be whole dwords", K);
+    }
+    p.img_bytes = (p.S * K + 1023) / 1024 * 1024;  // K-fold wide image, whole 1 KiB wave-instructions
     p.rest.seed_lo = (uint32_t)cfg->seed;
     p.rest.seed_hi = (uint32_t)(cfg->seed >> 32);
     p.rest.env_id_base = cfg->env_id_base;
@@ -177,7 +184,7 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
     for (int r = 0; r < W; ++r)
         for (int c = 0; c < W; ++c)
             if (r == 0 || r == W - 1 || c == 0 || c == W - 1)
-                memset(&tmpl[((size_t)r * W + c) * p.C], 255, (size_t)p.C);
+                memset(&tmpl[((size_t)r * W + c) * p.C * K], 255, (size_t)p.C * K);
     if ((e = hipMemcpy(const_cast<uint8_t*>(p.tmpl), tmpl.data(), tmpl_bytes, hipMemcpyHostToDevice)) != hipSuccess) {
         (void)hipFree(h->d_state); (void)hipFree(h->d_stats);
         free(h);
@@ -201,8 +208,8 @@ int msnake_destroy(msnake_handle h) {
 
 int msnake_obs_shape(msnake_handle h, int32_t* H, int32_t* W, int32_t* C) {
     if (int rc = check(h)) return rc;
-    if (H) *H = h->p.dim + 2;
-    if (W) *W = h->p.dim + 2;
+    if (H) *H = (h->p.dim + 2) * h->p.obs_scale;
+    if (W) *W = (h->p.dim + 2) * h->p.obs_scale;
     if (C) *C = h->p.C;
     return MSNAKE_OK;
 }
@@ -408,7 +415,7 @@ int msnake_get_stats(msnake_handle h, msnake_stats* out, int32_t reset) {
 
 const char* msnake_kernel_name(msnake_handle h) {
     if (check(h)) return "";
-    return msnake::step_kernel_name(h->cfg.rules, h->cfg.n_snakes);
+    return msnake::step_kernel_name(h->cfg.rules, h->cfg.n_snakes, h->cfg.obs_scale);
 }
 
 int64_t msnake_algorithmic_bytes_per_env_step(msnake_handle h) {
@@ -416,7 +423,7 @@ int64_t msnake_algorithmic_bytes_per_env_step(msnake_handle h) {
     // obs write + one read of per-cell occupancy + actions + reward/done +
     // per-snake and per-env scalar read-modify-write
     const msnake::StepParams& p = h->p;
-    return (int64_t)p.S + (int64_t)p.dim * p.dim + 4 * p.n_snakes + 5 + 16 * p.n_snakes + 16;
+    return (int64_t)p.S * p.obs_scale * p.obs_scale + (int64_t)p.dim * p.dim + 4 * p.n_snakes + 5 + 16 * p.n_snakes + 16;
 }
 
 }  // extern "C"

@@ -56,6 +56,7 @@ struct StepParams {
     int32_t lds_per_wave;  // bytes of LDS per env: padded image + occupancy bytes
     int32_t img_bytes;     // S rounded up to 1 KiB
     int32_t action_stride;
+    int32_t obs_scale;     // fused WarpFrame replication factor (1, 4 or 7)
     // state (HBM, owned by the handle): ONE allocation
     //   [hdr: nenv x 256 B][body0: nenv x n_snakes x 128 B][tmpl: img_bytes][ring: nenv x n_snakes x cap x 2 B]
     //   adversarial only: [fl0: nenv x 128 B][flist: nenv x fcap x 2 B] (fruit list chunk 0 / complete)
@@ -76,7 +77,7 @@ struct StepParams {
 
 hipError_t launch_stats(uint32_t* hdr, int nenv, unsigned long long* stats, int clear, hipStream_t stream);
 hipError_t launch_step(const StepParams& p, int rules, int mode, int envs_per_block, hipStream_t stream);
-const char* step_kernel_name(int rules, int n_snakes);
+const char* step_kernel_name(int rules, int n_snakes, int obs_scale);
 
 }  // namespace msnake
 

@@ -102,10 +102,13 @@ __device__ __forceinline__ bool in_grid(uint32_t cell, int dim) {
 typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
 
 // MODE 0: step, 1: reset every env (msnake_reset), 2: render only (msnake_render)
+// K: integer pixel replication of the observation fused into the copy-out (the reference's WarpFrame,
+//    src/utils.py:15-31: cv2.resize to 84x84 with INTER_AREA, which for the exact integer up-scales
+//    used there -- 21->84 = x4, 12->84 = x7 -- is plain pixel replication)
 // The first 13 kernel-argument dwords (pointers + packed configuration) are preloaded into SGPRs
 // by the dispatcher (-mllvm -amdgpu-kernarg-preload-count), so a wave can issue its state loads
 // without waiting for a scalar-memory round trip; the rarely used rest comes by value behind them.
-template <int RULES, int NS, int MODE>
+template <int RULES, int NS, int MODE, int K>
 __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     uint8_t* __restrict__ state, uint8_t* __restrict__ obs, const int32_t* __restrict__ actions,
     float* __restrict__ rew_out, uint8_t* __restrict__ done_out, const int32_t nenv, const uint32_t pk0,
@@ -124,7 +127,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     const uint32_t max_steps = pk0 >> 16;
     const int S = (int)(pk1 & 0xFFFFu), cap = (int)(pk1 >> 16);
     const int W = dim + 2, n2 = dim * dim;
-    const int img_bytes = (S + 1023) & ~1023;  // image padded to whole 1 KiB wave-instructions
+    // LDS image: W rows of W*K pixels (already replicated horizontally when K > 1), padded to
+    // whole 1 KiB wave-instructions
+    const int img_bytes = (S * K + 1023) & ~1023;
     const int occ_bytes = (n2 + 15) & ~15;
     uint8_t* img = smem + (size_t)wave * (size_t)(img_bytes + occ_bytes);  // observation being composed
     uint8_t* occ = img + img_bytes;                                        // respawn occupancy
@@ -618,16 +623,20 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             // which the reference paints last: skip them
             for_each_fruit((int)rdlane(hv, HDR_NLIST), [&](int, uint32_t cell) {
                 if (!in_grid(cell, dim)) return;
-                const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * C;
+                const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * (C * K);
 #pragma unroll
-                for (int v = 0; v < VIEWS; ++v) px[off + 3 * v] = 255;
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int v = 0; v < VIEWS; ++v) px[off + k * C + 3 * v] = 255;
             });
         } else if (lane >= 32 && lane < 32 + nf) {
             const uint32_t cell = hv & 0xFFFFu;
             if (in_grid(cell, dim)) {
-                const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * C;
+                const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * (C * K);
 #pragma unroll
-                for (int v = 0; v < VIEWS; ++v) px[off + 3 * v] = 255;
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int v = 0; v < VIEWS; ++v) px[off + k * C + 3 * v] = 255;
             }
         }
         // snakes in index order, head over body ([S]:46-50, draw_snake :24-33); LDS writes of one
@@ -639,28 +648,47 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             if (RULES == MSNAKE_RULES_NEW_WORLD && !((flags >> j) & 1u)) continue;  // [N]:219
             for_each_piece(j, cr[j], (int)(w0 & 0xFFFFu), (int)(w0 >> 16), [&](int i, uint32_t cell) {
                 if (!in_grid(cell, dim)) return;
-                const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * C;
+                const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * (C * K);
                 const bool hd1 = i == 0;
 #pragma unroll
-                for (int v = 0; v < VIEWS; ++v) {
-                    // body/head: self green (0,204,0)/(191,242,191), other blue (0,51,204)/(128,154,230)
-                    const bool self = v == j;
-                    px[off + 3 * v + 0] = hd1 ? (self ? 191 : 128) : 0;
-                    px[off + 3 * v + 1] = hd1 ? (self ? 242 : 154) : (self ? 204 : 51);
-                    px[off + 3 * v + 2] = hd1 ? (self ? 191 : 230) : (self ? 0 : 204);
-                }
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int v = 0; v < VIEWS; ++v) {
+                        // body/head: self green (0,204,0)/(191,242,191), other blue (0,51,204)/(128,154,230)
+                        const bool self = v == j;
+                        px[off + k * C + 3 * v + 0] = hd1 ? (self ? 191 : 128) : 0;
+                        px[off + k * C + 3 * v + 1] = hd1 ? (self ? 242 : 154) : (self ? 204 : 51);
+                        px[off + k * C + 3 * v + 2] = hd1 ? (self ? 191 : 230) : (self ? 0 : 204);
+                    }
             });
         }
         wave_sync();
-        // ---- 7. LDS image -> HBM: 16 bytes per lane, 1 KiB contiguous per wave instruction.  The
-        //         3969-byte images are not 16-byte multiples, so the global side is byte-aligned
-        //         (the hardware splits the few lines that straddle); the last S%16 bytes go singly.
-        uint8_t* obs_env = obs + (size_t)e * S;
-        const int nfull = S >> 4;
-        for (int k = lane; k < nfull; k += 64)
-            *reinterpret_cast<uint4_unaligned*>(obs_env + 16 * k) = reinterpret_cast<const uint4*>(img)[k];
-        const int tail = (nfull << 4) + lane;
-        if (tail < S) obs_env[tail] = img[tail];
+        if (K == 1) {
+            // ---- 7. LDS image -> HBM: 16 bytes per lane, 1 KiB contiguous per wave instruction.
+            //         The 3969-byte images are not 16-byte multiples, so the global side is
+            //         byte-aligned (the hardware splits the few lines that straddle); the last
+            //         S%16 bytes go singly.
+            uint8_t* obs_env = obs + (size_t)e * S;
+            const int nfull = S >> 4;
+            for (int k = lane; k < nfull; k += 64)
+                *reinterpret_cast<uint4_unaligned*>(obs_env + 16 * k) = reinterpret_cast<const uint4*>(img)[k];
+            const int tail = (nfull << 4) + lane;
+            if (tail < S) obs_env[tail] = img[tail];
+        } else {
+            // ---- 7'. fused WarpFrame: the LDS image is already K-fold wide; every row of it is
+            //          stored to K consecutive output rows.  Rows are W*K*C bytes = a whole number of
+            //          dwords (84 pixels), so each lane moves aligned dwords: one LDS read feeds K
+            //          stores of 256 contiguous bytes per wave instruction.
+            uint32_t* out = reinterpret_cast<uint32_t*>(obs + (size_t)e * S * (K * K));
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(img);
+            const int rowdw = (W * K * C) >> 2;
+            for (int r = 0; r < W; ++r)
+                for (int q = lane; q < rowdw; q += 64) {
+                    const uint32_t v = src[r * rowdw + q];
+#pragma unroll
+                    for (int rr = 0; rr < K; ++rr) out[(size_t)(r * K + rr) * rowdw + q] = v;
+                }
+        }
     }
 }
 
@@ -694,16 +722,16 @@ hipError_t launch_stats(uint32_t* hdr, int nenv, unsigned long long* stats, int 
 // ------------------------------------------------------------------------------------------------
 // launch glue (called from the C-ABI in msnake_capi.hip)
 // ------------------------------------------------------------------------------------------------
-template <int RULES, int NS>
-static hipError_t launch_ns(const StepParams& p, int mode, int epb, hipStream_t stream) {
+template <int RULES, int NS, int K>
+static hipError_t launch_k(const StepParams& p, int mode, int epb, hipStream_t stream) {
     const dim3 grid((unsigned)((p.nenv + epb - 1) / epb));
     const dim3 block(64u * (unsigned)epb);
     const uint32_t pk0 = (uint32_t)p.dim | ((uint32_t)p.n_fruits << 6) | ((uint32_t)p.action_stride << 12) |
                          ((uint32_t)(p.auto_reset ? 1 : 0) << 15) | ((uint32_t)p.rest.max_steps << 16);
     const uint32_t pk1 = (uint32_t)p.S | ((uint32_t)p.rest.cap << 16);
     const size_t lds = (size_t)p.lds_per_wave * (size_t)epb;
-#define MSNAKE_LAUNCH(M)                                                                                  \
-    hipLaunchKernelGGL((msnake_step_kernel<RULES, NS, M>), grid, block, lds, stream, p.state, p.obs, p.actions, \
+#define MSNAKE_LAUNCH(M)                                                                                       \
+    hipLaunchKernelGGL((msnake_step_kernel<RULES, NS, M, K>), grid, block, lds, stream, p.state, p.obs, p.actions, \
                        p.rest.rew, p.rest.done, p.nenv, pk0, pk1, p.rest)
     switch (mode) {
         case 0: MSNAKE_LAUNCH(0); break;
@@ -712,6 +740,16 @@ static hipError_t launch_ns(const StepParams& p, int mode, int epb, hipStream_t 
     }
 #undef MSNAKE_LAUNCH
     return hipGetLastError();
+}
+
+template <int RULES, int NS>
+static hipError_t launch_ns(const StepParams& p, int mode, int epb, hipStream_t stream) {
+    switch (p.obs_scale) {
+        case 1: return launch_k<RULES, NS, 1>(p, mode, epb, stream);
+        case 4: return launch_k<RULES, NS, 4>(p, mode, epb, stream);
+        case 7: return launch_k<RULES, NS, 7>(p, mode, epb, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 template <int RULES>
@@ -738,8 +776,8 @@ hipError_t launch_step(const StepParams& p, int rules, int mode, int epb, hipStr
 }
 
 static char g_kname[64];
-const char* step_kernel_name(int rules, int n_snakes) {
-    snprintf(g_kname, sizeof(g_kname), "msnake_step_kernel<%d, %d, 0>", rules, n_snakes);
+const char* step_kernel_name(int rules, int n_snakes, int obs_scale) {
+    snprintf(g_kname, sizeof(g_kname), "msnake_step_kernel<%d, %d, 0, %d>", rules, n_snakes, obs_scale);
     return g_kname;
 }
 

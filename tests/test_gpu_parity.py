@@ -159,6 +159,30 @@ def test_ragged_batch_sizes_and_unaligned_images(num_envs):
     env.close()
 
 
+@pytest.mark.parametrize("dim,n_snakes,rules,scale", [(19, 3, "snake_env", 4), (10, 1, "snake_env", 7),
+                                                      (10, 2, "new_world", 7), (10, 2, "adversarial", 7),
+                                                      (19, 2, "snake_env", 4)])
+def test_fused_warpframe_is_pixel_replication(dim, n_snakes, rules, scale):
+    """obs_scale = the reference's WarpFrame (src/utils.py:15-31): 84x84 frames.  cv2 is not
+    installed, so parity with cv2.resize(INTER_AREA) is UNPINNED; the contract tested here is exact
+    integer pixel replication (np.repeat on both axes) of the oracle's native frame."""
+    from oracle.snake_oracle import Oracle
+    n = 300
+    env = _mk(num_envs=n, dim=dim, n_snakes=n_snakes, rules=rules, seed=12, obs_scale=scale)
+    ora = Oracle(n, dim=dim, n_snakes=n_snakes, rules=rules, seed=12)
+    assert env.obs_shape[:2] == (84, 84)
+    up = lambda o: np.repeat(np.repeat(o, scale, axis=1), scale, axis=2)
+    assert np.array_equal(env.reset(), up(ora.reset()))
+    rs = np.random.default_rng(3)
+    for t in range(40):
+        act = rs.integers(0, 5, (n, n_snakes)).astype(np.int32)
+        obs, rew, done, _ = env.step(act)
+        o_obs, o_rew, o_done, _, _, _ = ora.step(act)
+        assert np.array_equal(rew, o_rew) and np.array_equal(done, o_done.astype(bool)), t
+        assert np.array_equal(obs, up(o_obs)), t
+    env.close()
+
+
 def test_sharding_is_invisible():
     """Two handles owning global envs [0,1024) and [1024,2048) == one handle owning [0,2048)."""
     whole = _mk(num_envs=2048, dim=19, n_snakes=3, rules="snake_env", seed=5)

@@ -62,7 +62,7 @@ def test_create_argument_checks_before_touching_the_gpu():
     sz = ctypes.sizeof(msnake._capi.MsnakeConfig)
     for kw, needle in [(dict(num_envs=0), b"num_envs"), (dict(dim=1), b"dim"), (dict(dim=63), b"dim"),
                        (dict(n_snakes=4), b"n_snakes"), (dict(n_fruits=2), b"n_fruits"), (dict(rules=7), b"rules"), (dict(rules=2, n_snakes=4, n_fruits=4), b"n_snakes"),
-                       (dict(max_steps=0), b"max_steps"), (dict(obs_scale=4), b"obs_scale")]:
+                       (dict(max_steps=0), b"max_steps"), (dict(obs_scale=3), b"obs_scale")]:
         f = dict(struct_size=sz, device=0, num_envs=4, dim=19, n_snakes=3, n_fruits=3, rules=0, max_steps=2000,
                  auto_reset=1, obs_scale=1, seed=0, env_id_base=0)
         f.update(kw)

@@ -16,13 +16,14 @@ def main():
     ap.add_argument("--snakes", type=int, default=3)
     ap.add_argument("--rules", default="snake_env")
     ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--scale", type=int, default=1)
     args = ap.parse_args()
     import torch
     import msnake
 
     dev = torch.device("cuda", 0)
     for n in args.envs:
-        env = msnake.MultiSnakeVecEnv(n, dim=args.dim, n_snakes=args.snakes, rules=args.rules, seed=0, device=dev)
+        env = msnake.MultiSnakeVecEnv(n, dim=args.dim, n_snakes=args.snakes, rules=args.rules, seed=0, device=dev, obs_scale=args.scale)
         env.reset_device()
         T = 64
         tape = torch.randint(0, 5, (T, n, args.snakes), dtype=torch.int32, device=dev)
