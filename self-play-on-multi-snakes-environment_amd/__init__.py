@@ -13,3 +13,4 @@ from .vec_env import GYM_IDS, LazyInfos, MultiSnakeVecEnv, make, normalize_actio
 
 __all__ = ["MultiSnakeVecEnv", "make", "GYM_IDS", "LazyInfos", "normalize_actions", "Box", "Discrete", "_capi",
            "shard_range", "gather_stats", "make_sharded"]
+# msnake.selfplay (PyTorch self-play PPO driver) is imported on demand: `from msnake import selfplay`

@@ -239,3 +239,21 @@ def test_errors_are_exceptions():
     env.close()
     with pytest.raises(RuntimeError, match="handle"):
         env.step_device(torch.zeros((4, 2), dtype=torch.int32, device="cuda"))
+
+
+def test_selfplay_ppo_rollouts_end_to_end():
+    """BASELINE configs[4] shape at reduced batch: 2 snakes, 19x19, PyTorch policy on the same GPU
+    driving the HIP env through step_device, a few PPO updates; checks plumbing, not learning."""
+    import torch
+    from msnake import selfplay
+    env = _mk(num_envs=256, dim=19, n_snakes=2, rules="snake_env", seed=3)
+    model, hist = selfplay.learn(env, nsteps=16, total_timesteps=256 * 16 * 3, nminibatches=4, log_fn=None)
+    assert len(hist) == 3 and hist[-1]["total_timesteps"] == 256 * 16 * 3
+    for k in ("eprewmean 100", "eplenmean", "policy_loss", "value_loss", "policy_entropy", "approxkl", "clipfrac",
+              "explained_variance", "num_opponents", "fps"):
+        assert k in hist[-1]
+    assert np.isfinite(hist[-1]["policy_loss"]) and 0 < hist[-1]["policy_entropy"] <= np.log(5) + 1e-3
+    st = env.stats()
+    assert st["env_steps"] == 256 * 16 * 3 and st["errors"] == 0 and st["episodes"] > 0
+    assert next(model.parameters()).is_cuda
+    env.close()

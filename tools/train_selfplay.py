@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Self-play PPO on the HIP env (BASELINE.json configs[4]: 4096 envs, 2 snakes, 19x19).
+    python tools/train_selfplay.py --envs 4096 --snakes 2 --timesteps 2000000 --csv ppo.csv"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # no exhaustive convolution search on first use
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--snakes", type=int, default=2)
+    ap.add_argument("--dim", type=int, default=19)
+    ap.add_argument("--rules", default="snake_env")
+    ap.add_argument("--nsteps", type=int, default=64)
+    ap.add_argument("--timesteps", type=int, default=int(2e6))
+    ap.add_argument("--scale", type=int, default=1, help="4 = 84x84 frames (nature_cnn) at dim 19")
+    ap.add_argument("--csv", default=None)
+    ap.add_argument("--monitor", default=None)
+    args = ap.parse_args()
+    import msnake
+    from msnake import selfplay
+
+    env = msnake.MultiSnakeVecEnv(args.envs, dim=args.dim, n_snakes=args.snakes, rules=args.rules, seed=0,
+                                  obs_scale=args.scale)
+    selfplay.learn(env, nsteps=args.nsteps, total_timesteps=args.timesteps, csv_path=args.csv,
+                   monitor_path=args.monitor)
+    print(env.stats())
+    env.close()
+
+
+if __name__ == "__main__":
+    main()
