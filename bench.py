@@ -144,6 +144,29 @@ def main():
 
     st = env.stats()
     assert st["errors"] == 0 and st["env_steps"] == K * n, st
+
+    # secondary figure: the same K steps through msnake_rollout_tape (ONE persistent launch per tape
+    # chunk, env state kept in registers across steps).  Only usable when the actions of several
+    # steps exist up front, so it is reported beside the headline, not as it.
+    rollout = None
+    if rank == 0 and not args.python_loop:
+        def run_rollout(nsteps):
+            k = 0
+            while k < nsteps:
+                m = min(nsteps - k, T)
+                msnake._capi.check(L.msnake_rollout_tape(h, tape.data_ptr(), N_SNAKES, m, obs.data_ptr(), 0,
+                                                         rew.data_ptr(), done.data_ptr(), info.data_ptr(), 0,
+                                                         env._stream()), "msnake_rollout_tape")
+                k += m
+        run_rollout(Wm)
+        torch.cuda.synchronize()
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record()
+        run_rollout(K)
+        r1.record()
+        torch.cuda.synchronize()
+        rollout = r0.elapsed_time(r1) * 1e3 / K  # us per step
+        env.stats(reset=True)
     # the only collective of the path: all-gather of the per-rank episode statistics (RCCL)
     rec = torch.tensor([st["episodes"], st["ep_len_sum"], st["ep_return_sum"], st["env_steps"]],
                        dtype=torch.int64, device=dev)
@@ -179,6 +202,12 @@ def main():
                          "kernel": env.kernel_name(), "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
+        if rollout is not None:
+            out["rollout_tape"] = {
+                "what": "same steps via msnake_rollout_tape: one persistent launch per 256-step tape chunk",
+                "us_per_step": round(rollout, 3), "env_steps_per_s": round(n / rollout * 1e6, 1),
+                "algorithmic_GBs": round(bytes_per_launch / rollout / 1e3, 1),
+                "frac_of_hbm_peak": round(bytes_per_launch / rollout / 1e3 / HBM_PEAK_GBS, 4)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(tape_h)
         print(json.dumps(out), flush=True)

@@ -122,6 +122,15 @@ int msnake_step_tape(msnake_handle h, const int32_t* actions_dev, int32_t action
                      uint8_t* obs_dev, size_t obs_step_stride, float* rew_dev, uint8_t* done_dev,
                      msnake_info* info_dev, size_t scalar_step_stride, void* stream);
 
+/* Same contract and same results as msnake_step_tape, but ONE persistent launch: every wave keeps
+ * its env in registers across the n_steps steps, so there is no per-step launch boundary and no
+ * per-step state round trip.  For callers that have the actions of several steps up front
+ * (scripted / random opponents, evaluation replays, benchmarks); a policy in the loop needs
+ * msnake_step. */
+int msnake_rollout_tape(msnake_handle h, const int32_t* actions_dev, int32_t action_stride, int32_t n_steps,
+                        uint8_t* obs_dev, size_t obs_step_stride, float* rew_dev, uint8_t* done_dev,
+                        msnake_info* info_dev, size_t scalar_step_stride, void* stream);
+
 /* Canonical per-env state as int32 words (blocking; test / checkpoint path):
  *  [0] t  [1] ctr_lo  [2] ctr_hi  [3] spare_fruits  [4] ep_len  [5] ep_return (f32 bits)
  *  [6] n_fruits_cur  [7] n_snakes, then n_fruits_cur x (c0,c1), then per snake:

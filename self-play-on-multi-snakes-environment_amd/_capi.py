@@ -15,7 +15,7 @@ RULE_NAMES = {v: k for k, v in RULES.items()}
 # every extern "C" symbol include/msnake.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "msnake_abi_version", "msnake_last_error", "msnake_create", "msnake_destroy", "msnake_obs_shape",
-    "msnake_reset", "msnake_step", "msnake_step_tape", "msnake_get_state", "msnake_set_state",
+    "msnake_reset", "msnake_step", "msnake_step_tape", "msnake_rollout_tape", "msnake_get_state", "msnake_set_state",
     "msnake_render", "msnake_get_stats", "msnake_kernel_name", "msnake_algorithmic_bytes_per_env_step",
 ]
 
@@ -56,6 +56,7 @@ def load():
     L.msnake_render.argtypes = [vp, u8p, vp]
     L.msnake_step.argtypes = [vp, vp, i32, u8p, vp, vp, vp, vp]
     L.msnake_step_tape.argtypes = [vp, vp, i32, i32, u8p, ctypes.c_size_t, vp, vp, vp, ctypes.c_size_t, vp]
+    L.msnake_rollout_tape.argtypes = L.msnake_step_tape.argtypes
     L.msnake_get_state.argtypes = [vp, i32, vp, i32]
     L.msnake_set_state.argtypes = [vp, i32, vp, i32]
     L.msnake_get_stats.argtypes = [vp, ctypes.POINTER(MsnakeStats), i32]
@@ -64,7 +65,7 @@ def load():
     L.msnake_algorithmic_bytes_per_env_step.argtypes = [vp]
     L.msnake_algorithmic_bytes_per_env_step.restype = ctypes.c_int64
     for name in ("msnake_create", "msnake_destroy", "msnake_obs_shape", "msnake_reset", "msnake_render",
-                 "msnake_step", "msnake_step_tape", "msnake_get_state", "msnake_set_state", "msnake_get_stats"):
+                 "msnake_step", "msnake_step_tape", "msnake_rollout_tape", "msnake_get_state", "msnake_set_state", "msnake_get_stats"):
         getattr(L, name).restype = ctypes.c_int
     _lib = L
     return L

@@ -267,6 +267,31 @@ int msnake_step_tape(msnake_handle h, const int32_t* actions_dev, int32_t action
     return MSNAKE_OK;
 }
 
+int msnake_rollout_tape(msnake_handle h, const int32_t* actions_dev, int32_t action_stride, int32_t n_steps, uint8_t* obs_dev,
+                        size_t obs_step_stride, float* rew_dev, uint8_t* done_dev, msnake_info* info_dev,
+                        size_t scalar_step_stride, void* stream) {
+    if (int rc = check(h)) return rc;
+    if (n_steps < 1) return fail(MSNAKE_E_ARG, "n_steps must be >= 1");
+    if (!actions_dev || !rew_dev || !done_dev) return fail(MSNAKE_E_ARG, "msnake_rollout_tape: actions/rew/done must not be NULL");
+    if (action_stride < h->p.n_snakes || action_stride > 7)
+        return fail(MSNAKE_E_ARG, "action_stride %d must be in [n_snakes=%d, 7]", action_stride, h->p.n_snakes);
+    if (((uintptr_t)actions_dev & 3) || ((uintptr_t)rew_dev & 3) || ((uintptr_t)info_dev & 15))
+        return fail(MSNAKE_E_ALIGN, "actions/rew must be 4-byte and info 16-byte aligned");
+    msnake::StepParams p = h->p;
+    p.actions = actions_dev; p.action_stride = action_stride;
+    p.obs = obs_dev; p.rest.rew = rew_dev; p.rest.done = done_dev; p.rest.info = info_dev;
+    p.rest.n_steps = n_steps;
+    p.rest.obs_step_stride = obs_step_stride;
+    p.rest.scalar_step_stride = scalar_step_stride;
+    DeviceGuard guard(h->cfg.device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = msnake::launch_step(p, h->cfg.rules, 3, h->epb, s);
+    if (e != hipSuccess) return fail(MSNAKE_E_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    h->last_stream = s;
+    h->env_steps += (int64_t)h->p.nenv * n_steps;
+    return MSNAKE_OK;
+}
+
 int msnake_get_state(msnake_handle h, int32_t env, int32_t* words, int32_t cap_words) {
     if (int rc = check(h)) return rc;
     if (env < 0 || env >= h->p.nenv) return fail(MSNAKE_E_ARG, "env %d out of range", env);

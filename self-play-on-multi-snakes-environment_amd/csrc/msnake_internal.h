@@ -47,7 +47,9 @@ struct StepRest {
     int32_t cap;                 // ring capacity in cells (multiple of 64)
     int32_t max_steps;
     uint32_t dbg_stage;          // timing-only early exits (MSNAKE_DBG_STAGES builds)
-    int32_t reserved;
+    int32_t n_steps;             // MODE 3 (msnake_rollout_tape): steps per launch
+    uint64_t obs_step_stride;    // MODE 3: bytes between consecutive steps' observations (0 = overwrite)
+    uint64_t scalar_step_stride; // MODE 3: elements between consecutive steps' rew/done/info
 };
 
 struct StepParams {

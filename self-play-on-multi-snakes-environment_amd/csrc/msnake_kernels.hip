@@ -152,7 +152,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #pragma unroll
     for (int s = 0; s < NS; ++s) cr[s] = body0_g[s * 64 + lane];
     int actv = 0;
-    if (MODE == 0 && lane < NS) actv = actions[(size_t)e * action_stride + lane];
+    constexpr bool STEPS = MODE == 0 || MODE == 3;  // MODE 3: n_steps steps of an action tape in one launch
+    if (STEPS && lane < NS) actv = actions[(size_t)e * action_stride + lane];
     // adversarial rules keep a growing fruit LIST ([A]:183-185 appends dead bodies to it): entries
     // 0..63 in a VGPR like a body chunk (lane l = entry l), the complete list in HBM behind the rings
     const int fcap = (NS + NS * (n2 + 2) + 63) & ~63;
@@ -164,22 +165,6 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         fl0_g = fl0_all + (size_t)e * 64;
         flist_g = fl0_all + (size_t)nenv * 64 + (size_t)e * fcap;
         fr = fl0_g[lane];
-    }
-
-    // background image (black interior, white wall ring): one L1/L2-resident copy shared by every
-    // wave, a whole number of 1 KiB wave-instructions so that no lane needs a predicate.
-    // (Storing the background to HBM right here, ahead of the logic, was measured and is SLOWER:
-    //  the 16 MB of early stores clog each CU's memory pipe in front of every later access.)
-    if (obs) {
-        const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl) + lane;
-        uint4* dst = reinterpret_cast<uint4*>(img) + lane;
-        int k = 0;
-        const int nk = img_bytes >> 10;
-        for (; k + 4 <= nk; k += 4) {
-            const uint4 t0 = tsrc[(k + 0) * 64], t1 = tsrc[(k + 1) * 64], t2 = tsrc[(k + 2) * 64], t3 = tsrc[(k + 3) * 64];
-            dst[(k + 0) * 64] = t0; dst[(k + 1) * 64] = t1; dst[(k + 2) * 64] = t2; dst[(k + 3) * 64] = t3;
-        }
-        for (; k < nk; ++k) dst[k * 64] = tsrc[k * 64];
     }
 
     // ---- RNG: randint(n) = (u32 * n) >> 32 on draw number ctr (kept in the record).  Slow paths
@@ -210,7 +195,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             if (i < s_len) {
                 int idx = s_hp + i;
                 idx = idx >= cap ? idx - cap : idx;
-                f(i, (uint32_t)ring_g[(size_t)s * cap + idx]);
+                f(i, (uint32_t)__hip_atomic_load(&ring_g[(size_t)s * cap + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
         }
     };
@@ -220,7 +205,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         if (lane < nlist) f(lane, fr);
         for (int base = 64; base < nlist; base += 64) {
             const int i = base + lane;
-            if (i < nlist) f(i, (uint32_t)flist_g[i]);
+            if (i < nlist) f(i, (uint32_t)__hip_atomic_load(&flist_g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
     };
     // fruits (of any rule set) lying on `cell`: how many, wave-uniform
@@ -230,7 +215,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             int n = __builtin_popcountll(ballot(lane < nlist && fr == cell));
             for (int base = 64; base < nlist; base += 64) {
                 const int i = base + lane;
-                n += __builtin_popcountll(ballot(i < nlist && (uint32_t)flist_g[i < nlist ? i : 0] == cell));
+                n += __builtin_popcountll(ballot(i < nlist && (uint32_t)__hip_atomic_load(&flist_g[i < nlist ? i : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cell));
             }
             return n;
         }
@@ -325,7 +310,37 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     }
 
     DBG_EXIT(1)
-    if (MODE == 0) {
+    const int n_steps = MODE == 3 ? p.n_steps : 1;
+    float* rew_t = rew_out;
+    uint8_t* done_t = done_out;
+    msnake_info* info_t = p.info;
+    uint8_t* obs_t = obs;
+#pragma nounroll
+    for (int step_i = 0; step_i < n_steps; ++step_i) {
+    if (MODE == 3 && step_i > 0) {  // next row of the action tape; outputs advance by their strides
+        actions += (size_t)nenv * action_stride;
+        if (lane < NS) actv = actions[(size_t)e * action_stride + lane];
+        rew_t += p.scalar_step_stride; done_t += p.scalar_step_stride;
+        if (info_t) info_t += p.scalar_step_stride;
+        if (obs_t) obs_t += p.obs_step_stride;
+    }
+    // background image (black interior, white wall ring): one L1/L2-resident copy shared by every
+    // wave, a whole number of 1 KiB wave-instructions so that no lane needs a predicate.
+    // (Storing the background to HBM right here, ahead of the logic, was measured and is SLOWER:
+    //  the 16 MB of early stores clog each CU's memory pipe in front of every later access.)
+    if (obs_t) {
+        const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl) + lane;
+        uint4* dst = reinterpret_cast<uint4*>(img) + lane;
+        int k = 0;
+        const int nk = img_bytes >> 10;
+        for (; k + 4 <= nk; k += 4) {
+            const uint4 t0 = tsrc[(k + 0) * 64], t1 = tsrc[(k + 1) * 64], t2 = tsrc[(k + 2) * 64], t3 = tsrc[(k + 3) * 64];
+            dst[(k + 0) * 64] = t0; dst[(k + 1) * 64] = t1; dst[(k + 2) * 64] = t2; dst[(k + 3) * 64] = t3;
+        }
+        for (; k < nk; ++k) dst[k * 64] = tsrc[k * 64];
+    }
+
+    if (STEPS) {
         float reward = 0.0f;
         // ---- 1. snake updates.  Fast path: all snakes at once on the VALU, lane s = snake s.
         //         Valid whenever no moving snake eats (then no fruit respawns, so the updates do
@@ -437,7 +452,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     bool built = false;
                     for (int base = 0; base < nlist; base += 64) {
                         const int i = base + lane;
-                        const uint32_t c = base == 0 ? fr : (uint32_t)flist_g[i < nlist ? i : 0];
+                        const uint32_t c = base == 0 ? fr : (uint32_t)__hip_atomic_load(&flist_g[i < nlist ? i : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         uint64_t m = ballot(i < nlist && c == (uint32_t)nh);
                         while (m) {
                             const int bit = __builtin_ffsll((long long)m) - 1;
@@ -492,7 +507,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     if (i < (int)ln[j]) {
                         int idx = (int)hp2[j] + i;
                         idx = idx >= cap ? idx - cap : idx;
-                        const uint32_t cell = ring_g[(size_t)j * cap + idx];
+                        const uint32_t cell = __hip_atomic_load(&ring_g[(size_t)j * cap + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                         for (int s = 0; s < NS; ++s)
                             hitl |= (cell == hd[s]) ? (1u << (4 * s + j)) : 0u;
@@ -594,27 +609,18 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         HV_SET(HDR_EP_RETURN, __float_as_uint(ep_ret));
         HV_SET(HDR_EP_LEN, ep_len);
         if (lane == 0) {
-            rew_out[e] = reward;
-            done_out[e] = done ? 1 : 0;
-            if (p.info) {
+            rew_t[e] = reward;
+            done_t[e] = done ? 1 : 0;
+            if (info_t) {
                 int4 iv;
                 iv.x = (int)__float_as_uint(out_ret); iv.y = (int)out_len; iv.z = num_alive; iv.w = done ? 1 : 0;
-                reinterpret_cast<int4*>(p.info)[e] = iv;
+                reinterpret_cast<int4*>(info_t)[e] = iv;
             }
         }
     }
 
-    DBG_EXIT(5)
-    // ---- 5. state write-back (fire and forget, overlaps the painting) ---------------------------
-    if (MODE != 2) {
-        hdr_g[lane] = hv;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) body0_g[s * 64 + lane] = (uint16_t)cr[s];
-        if (RULES == MSNAKE_RULES_ADVERSARIAL) fl0_g[lane] = (uint16_t)fr;
-    }
-
     // ---- 6. paint the observation over the background, in reference order ----------------------
-    if (obs) {
+    if (obs_t) {
         wave_sync();
         uint8_t* px = img;
         // fruits first ([S]:43-44): red in every view; the background is already black
@@ -668,7 +674,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             //         The 3969-byte images are not 16-byte multiples, so the global side is
             //         byte-aligned (the hardware splits the few lines that straddle); the last
             //         S%16 bytes go singly.
-            uint8_t* obs_env = obs + (size_t)e * S;
+            uint8_t* obs_env = obs_t + (size_t)e * S;
             const int nfull = S >> 4;
             for (int k = lane; k < nfull; k += 64)
                 *reinterpret_cast<uint4_unaligned*>(obs_env + 16 * k) = reinterpret_cast<const uint4*>(img)[k];
@@ -679,7 +685,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             //          stored to K consecutive output rows.  Rows are W*K*C bytes = a whole number of
             //          dwords (84 pixels), so each lane moves aligned dwords: one LDS read feeds K
             //          stores of 256 contiguous bytes per wave instruction.
-            uint32_t* out = reinterpret_cast<uint32_t*>(obs + (size_t)e * S * (K * K));
+            uint32_t* out = reinterpret_cast<uint32_t*>(obs_t + (size_t)e * S * (K * K));
             const uint32_t* src = reinterpret_cast<const uint32_t*>(img);
             const int rowdw = (W * K * C) >> 2;
             for (int r = 0; r < W; ++r)
@@ -690,6 +696,16 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 }
         }
     }
+    }  // step loop
+
+    // ---- 5. state write-back (once per launch) ---------------------------
+    if (MODE != 2) {
+        hdr_g[lane] = hv;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) body0_g[s * 64 + lane] = (uint16_t)cr[s];
+        if (RULES == MSNAKE_RULES_ADVERSARIAL) fl0_g[lane] = (uint16_t)fr;
+    }
+
 }
 
 // Sum the per-env logging totals into stats[0..4] (msnake_get_stats; off the step path).
@@ -736,6 +752,7 @@ static hipError_t launch_k(const StepParams& p, int mode, int epb, hipStream_t s
     switch (mode) {
         case 0: MSNAKE_LAUNCH(0); break;
         case 1: MSNAKE_LAUNCH(1); break;
+        case 3: MSNAKE_LAUNCH(3); break;
         default: MSNAKE_LAUNCH(2); break;
     }
 #undef MSNAKE_LAUNCH

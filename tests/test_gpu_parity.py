@@ -222,6 +222,67 @@ def test_step_tape_equals_single_steps():
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("rules,dim,ns,nf", [("snake_env", 19, 3, 3), ("new_world", 10, 2, 4), ("adversarial", 10, 3, 3)])
+def test_rollout_tape_persistent_launch_equals_single_steps(rules, dim, ns, nf):
+    """msnake_rollout_tape (one persistent launch for T steps) == T msnake_step launches."""
+    import torch
+    import msnake
+    n, T = 777, 48
+    a = _mk(num_envs=n, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=21)
+    b = _mk(num_envs=n, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=21)
+    a.reset(); b.reset()
+    tape = torch.randint(0, 5, (T, n, ns), dtype=torch.int32, device=a.device)
+    H, W, C = a.obs_shape
+    obs = torch.empty((T, n, H, W, C), dtype=torch.uint8, device=a.device)
+    rew = torch.empty((T, n), dtype=torch.float32, device=a.device)
+    done = torch.empty((T, n), dtype=torch.uint8, device=a.device)
+    info = torch.empty((T, n, 4), dtype=torch.int32, device=a.device)
+    msnake._capi.check(a._L.msnake_rollout_tape(a._h, tape.data_ptr(), ns, T, obs.data_ptr(), n * H * W * C,
+                                                rew.data_ptr(), done.data_ptr(), info.data_ptr(), n, a._stream()))
+    for t in range(T):
+        o, r, d, i = b.step_device(tape[t])
+        assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(d, done[t]) and torch.equal(i, info[t]), t
+    for e in range(0, n, 37):
+        assert _state(a, e) == _state(b, e)
+    assert a.stats() == b.stats()
+    # in-place outputs (stride 0): the last step's outputs remain
+    msnake._capi.check(a._L.msnake_rollout_tape(a._h, tape.data_ptr(), ns, 5, obs.data_ptr(), 0, rew.data_ptr(),
+                                                done.data_ptr(), info.data_ptr(), 0, a._stream()))
+    for t in range(5):
+        o, r, d, i = b.step_device(tape[t])
+    assert torch.equal(o, obs[0]) and torch.equal(r, rew[0]) and torch.equal(d, done[0])
+    a.close(); b.close()
+
+
+def test_rollout_tape_with_bodies_longer_than_one_chunk():
+    """Bodies over 64 cells re-read ring cells the same wave stored earlier in the same launch."""
+    import torch
+    import msnake
+    from oracle.snake_oracle import Oracle
+    case = [c for c in edge_cases() if c["name"] == "S_full_board_10"][0]
+    env = _mk(num_envs=3, dim=10, n_snakes=1, rules="snake_env", seed=case["seed"], env_id_base=case["env_id"], auto_reset=False)
+    ora = Oracle(3, dim=10, n_snakes=1, rules="snake_env", seed=case["seed"], env_id_base=case["env_id"], auto_reset=False)
+    env.reset(); ora.reset()
+    st = dict(case["state0"]); st["grow_to"] = [90]; st["snakes"] = [st["snakes"][0][:80]]  # 80 cells, shrinking to 90? no: stays
+    # walk the boustrophedon backwards is impossible; instead let it advance along the free last row
+    for e in range(3):
+        _set_state(env, e, st); ora.set_state(e, st)
+    T = 6
+    acts = np.zeros((T, 3, 1), np.int32)  # keep heading (-1,0) along row 9... then it leaves the grid
+    tape = torch.from_numpy(acts).to(env.device)
+    H, W, C = env.obs_shape
+    obs = torch.empty((T, 3, H, W, C), dtype=torch.uint8, device=env.device)
+    rew = torch.empty((T, 3), dtype=torch.float32, device=env.device)
+    done = torch.empty((T, 3), dtype=torch.uint8, device=env.device)
+    msnake._capi.check(env._L.msnake_rollout_tape(env._h, tape.data_ptr(), 1, T, obs.data_ptr(), 3 * H * W * C,
+                                                  rew.data_ptr(), done.data_ptr(), None, 3, env._stream()))
+    for t in range(T):
+        o_obs, o_rew, o_done, _, _, _ = ora.step(acts[t])
+        assert np.array_equal(obs[t].cpu().numpy(), o_obs), t
+        assert np.array_equal(rew[t].cpu().numpy(), o_rew) and np.array_equal(done[t].cpu().numpy(), o_done), t
+    env.close()
+
+
 def test_errors_are_exceptions():
     import torch
     with pytest.raises(RuntimeError, match="n_snakes"):

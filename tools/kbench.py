@@ -51,6 +51,15 @@ def main():
                     done_k += m
             return run
 
+        def rollout(k):
+            done_k = 0
+            while done_k < k:
+                m = min(T, k - done_k)
+                msnake._capi.check(L.msnake_rollout_tape(h, tape.data_ptr(), args.snakes, m, obs.data_ptr(), 0,
+                                                         rew.data_ptr(), done.data_ptr(), info.data_ptr(), 0,
+                                                         env._stream()))
+                done_k += m
+
         def renders(k):
             for _ in range(k):
                 env.render_device()
@@ -61,7 +70,7 @@ def main():
 
         B = env.algorithmic_bytes_per_env_step() * n
         res = {"envs": n}
-        for name, fn in [("step", tape_steps(obs.data_ptr())), ("step_noobs", tape_steps(None)),
+        for name, fn in [("step", tape_steps(obs.data_ptr())), ("step_noobs", tape_steps(None)), ("rollout_step", rollout),
                          ("render", renders), ("reset", resets)]:
             us = timeit(fn, args.iters)
             res[name + "_us"] = round(us, 2)
