@@ -176,7 +176,11 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         uint32_t idx = ctr_lo - draw_base;
         if (!draws_valid || idx >= 64u) {
             const uint64_t gid = p.env_id_base + (uint64_t)e;
-            draws = philox_draws(ctr_lo, ctr_hi, lane, (uint32_t)gid, (uint32_t)(gid >> 32), p.seed_lo, p.seed_hi);
+            uint32_t k0 = p.seed_lo, k1 = p.seed_hi;
+            // slow path only: keep the ten-round key schedule from being hoisted to kernel entry,
+            // where it would pin 20 SGPRs for every wave
+            asm volatile("" : "+s"(k0), "+s"(k1));
+            draws = philox_draws(ctr_lo, ctr_hi, lane, (uint32_t)gid, (uint32_t)(gid >> 32), k0, k1);
             draw_base = ctr_lo; draws_valid = true; idx = 0;
         }
         const uint32_t u = rdlane(draws, (int)idx);
