@@ -64,6 +64,18 @@ __device__ __forceinline__ uint32_t shift_up1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false);
 }
 
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside each row of 16 (row_shr 1,2,4,8),
+// then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3 (lanes without a source add 0)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+    return x;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 (rocRAND's seed / subsequence / offset convention): draw i of global env g is word
 // (i & 3) of philox(counter = {i>>2, g}, key = seed).  Evaluated on the VALU with lane l computing
@@ -227,10 +239,15 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     };
 
     // ---- fruit respawn: [S]:202-217 safe_choose_cell == [N]:235-247 get_safe_cell --------------
-    uint64_t freemask = 0;  // lane c: ballot of the free cells of index chunk c
+    // occupancy is ONE BIT per cell index x = c1*dim + c0 in LDS (set with ds_or); lane c then owns
+    // the 64 cells of chunk c as a register bit mask, a DPP prefix sum over the per-lane free
+    // counts gives len(available) and locates the k-th free cell without any loop over cells.
+    uint64_t freemask = 0;   // lane c: free cells of chunk c
+    uint32_t freescan = 0;   // lane c: number of free cells in chunks 0..c
     int nfree = 0;
     auto build_free = [&]() {
-        for (int i = lane * 4; i < occ_bytes; i += 256) *reinterpret_cast<uint32_t*>(occ + i) = 0u;
+        uint32_t* occw = reinterpret_cast<uint32_t*>(occ);
+        for (int i = lane; i < ((n2 + 63) >> 6) * 2; i += 64) occw[i] = 0u;  // one bit per cell
         wave_sync();
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -238,34 +255,29 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             for_each_piece(j, cr[j], (int)(w0 & 0xFFFFu), (int)(w0 >> 16), [&](int, uint32_t cell) {
                 // used = c1*dim + c0; out-of-grid heads alias onto other cells or fall outside
                 const int used = ((int)(cell & 255u) - 1) * dim + ((int)(cell >> 8) - 1);
-                if ((uint32_t)used < (uint32_t)n2) occ[used] = 1;
+                if ((uint32_t)used < (uint32_t)n2) atomicOr(&occw[used >> 5], 1u << (used & 31));
             });
         }
         wave_sync();
-        nfree = 0; freemask = 0;
-        for (int c = 0; c * 64 < n2; ++c) {
-            const int idx = c * 64 + lane;
-            const uint64_t m = ballot(idx < n2 && occ[idx] == 0);
-            nfree += __builtin_popcountll(m);
-            if (lane == c) freemask = m;
-        }
+        const int base = lane * 64;
+        uint64_t occbits = ~0ull;
+        if (base < n2) occbits = *reinterpret_cast<const uint64_t*>(occ + lane * 8);
+        const int rem = n2 - base;  // cells of this chunk that exist
+        const uint64_t valid = rem >= 64 ? ~0ull : rem > 0 ? ((1ull << rem) - 1ull) : 0ull;
+        freemask = ~occbits & valid;
+        freescan = wave_scan_incl((uint32_t)__builtin_popcountll(freemask));
+        nfree = (int)rdlane(freescan, 63);
         wave_sync();
     };
     auto safe_cell = [&]() -> uint32_t {
         int x = 0;
         if (nfree > 0) {
-            int k = (int)randint((uint32_t)nfree);
-            for (int c = 0; c * 64 < n2; ++c) {
-                const uint64_t m = ((uint64_t)rdlane((uint32_t)(freemask >> 32), c) << 32) |
-                                   rdlane((uint32_t)freemask, c);
-                const int cnt = __builtin_popcountll(m);
-                if (k < cnt) {
-                    const uint64_t sel = ballot(((m >> lane) & 1ull) && (int)mbcnt(m) == k);
-                    x = c * 64 + (__builtin_ffsll((long long)sel) - 1);
-                    break;
-                }
-                k -= cnt;
-            }
+            const uint32_t k = randint((uint32_t)nfree);
+            const int L = __builtin_ffsll((long long)ballot(freescan > k)) - 1;  // chunk holding the k-th free cell
+            const uint64_t m = ((uint64_t)rdlane((uint32_t)(freemask >> 32), L) << 32) | rdlane((uint32_t)freemask, L);
+            const uint32_t kk = k - (rdlane(freescan, L) - (uint32_t)__builtin_popcountll(m));
+            const uint64_t sel = ballot(((m >> lane) & 1ull) && mbcnt(m) == kk);
+            x = L * 64 + (__builtin_ffsll((long long)sel) - 1);
         }
         return (uint32_t)(((x % dim + 1) << 8) | (x / dim + 1));
     };
