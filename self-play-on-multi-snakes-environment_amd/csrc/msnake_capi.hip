@@ -190,7 +190,12 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
         free(h);
         return fail(MSNAKE_E_HIP, "uploading the background image failed: %s", hipGetErrorString(e));
     }
+    if (const char* epb = getenv("MSNAKE_EPB")) {  // tuning knob: envs (waves) per workgroup, 1..4
+        const int v = atoi(epb);
+        if (v >= 1 && v <= h->epb) h->epb = v;
+    }
     if (const char* dbg = getenv("MSNAKE_DBG_STAGE")) p.rest.dbg_stage = (uint32_t)atoi(dbg);
+    if (const char* dbg = getenv("MSNAKE_DBG_BUF")) p.rest.dbg_buf = reinterpret_cast<unsigned long long*>(strtoull(dbg, nullptr, 0));
     h->magic = kMagic;
     *out = h;
     return MSNAKE_OK;

@@ -47,6 +47,7 @@ struct StepRest {
     int32_t cap;                 // ring capacity in cells (multiple of 64)
     int32_t max_steps;
     uint32_t dbg_stage;          // timing-only early exits (MSNAKE_DBG_STAGES builds)
+    unsigned long long* dbg_buf; // MSNAKE_DBG_STAGES builds: [nenv][8] s_memrealtime stamps (MSNAKE_DBG_BUF)
     int32_t n_steps;             // MODE 3 (msnake_rollout_tape): steps per launch
     uint64_t obs_step_stride;    // MODE 3: bytes between consecutive steps' observations (0 = overwrite)
     uint64_t scalar_step_stride; // MODE 3: elements between consecutive steps' rew/done/info

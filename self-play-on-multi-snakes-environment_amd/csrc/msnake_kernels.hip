@@ -148,12 +148,18 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #ifdef MSNAKE_DBG_STAGES
     const uint32_t dbg = p.dbg_stage;  // timing-only early exits
 #define DBG_EXIT(n) if (dbg == (n)) { if (hv == 0xDEADBEEFu) hdr_g[lane] = hv + cr[0] + (uint32_t)actv; return; }
+    // diagnostic build only: 100 MHz wall-clock stamps per wave, never read by the kernel itself
+#define STAMP(k) if (p.dbg_buf && lane == 0) p.dbg_buf[(size_t)e * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
+#define STAMP_FLAG(v) if (p.dbg_buf && lane == 0) p.dbg_buf[(size_t)e * 8 + 7] = (v)
 #else
 #define DBG_EXIT(n)
+#define STAMP(k)
+#define STAMP_FLAG(v)
 #endif
 
     // ---- 0. every load whose address depends only on the env index.  One allocation holds
     //         [records | chunk-0 bodies | background image | rings]: one preloaded pointer ---------
+    STAMP(0);
     uint32_t* hdr_g = reinterpret_cast<uint32_t*>(state) + (size_t)e * MSNAKE_HDR_WORDS;
     uint16_t* body0_all = reinterpret_cast<uint16_t*>(state + (size_t)nenv * (MSNAKE_HDR_WORDS * 4));
     uint16_t* body0_g = body0_all + (size_t)e * NS * 64;
@@ -385,6 +391,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             for (int f = 0; f < nf; ++f)
                 v_em |= ((uint32_t)v_nh == (rdlane(hv, HDR_FRUIT0 + f) & 0xFFFFu)) ? (1u << f) : 0u;
         }
+        STAMP(1);
         const uint64_t mvmask = ballot(v_moves);
         bool any_eat = ballot(v_moves && v_em != 0) != 0;
         if (RULES == MSNAKE_RULES_ADVERSARIAL) {
@@ -495,6 +502,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
         }
 
+        STAMP(2);
         DBG_EXIT(2)
         // ---- 2. head-vs-piece matrix: some piece of snake j other than s's own head lies on
         //         s's head.  [S] only needs "any j" per s; [N] needs the full matrix -------------
@@ -604,6 +612,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
         HV_SET(HDR_T, t);
 
+        STAMP(3);
         DBG_EXIT(4)
         // ---- 4. vec layer: episode statistics and auto reset -----------------------------------
         float ep_ret = __uint_as_float(rdlane(hv, HDR_EP_RETURN)) + reward;
@@ -624,6 +633,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
         HV_SET(HDR_EP_RETURN, __float_as_uint(ep_ret));
         HV_SET(HDR_EP_LEN, ep_len);
+        STAMP(4);
+        STAMP_FLAG((unsigned long long)(any_eat ? 1 : 0) | (done ? 2ull : 0ull));
         if (lane == 0) {
             rew_t[e] = reward;
             done_t[e] = done ? 1 : 0;
@@ -685,6 +696,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             });
         }
         wave_sync();
+        STAMP(5);
         if (K == 1) {
             // ---- 7. LDS image -> HBM: 16 bytes per lane, 1 KiB contiguous per wave instruction.
             //         The 3969-byte images are not 16-byte multiples, so the global side is
@@ -712,6 +724,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 }
         }
     }
+    STAMP(6);
     }  // step loop
 
     // ---- 5. state write-back (once per launch) ---------------------------

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Diagnostic (MSNAKE_DBG_STAGES build only): per-wave wall-clock stamps of one steady-state step.
+Prints, per stage, when the fastest / median / slowest wave reached it (us since the first wave
+started) split by which slow path the wave took."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+buf = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+os.environ["MSNAKE_DBG_BUF"] = hex(buf.data_ptr())
+import msnake
+
+env = msnake.MultiSnakeVecEnv(n, dim=19, n_snakes=3, seed=0)
+env.reset_device()
+tape = torch.randint(0, 5, (300, n, 3), dtype=torch.int32, device="cuda")
+for t in range(200):
+    env.step_device(tape[t])
+names = ["entry", "loads", "move", "alive", "reset+stats", "painted", "stores issued"]
+acc = {}
+for rep in range(20):
+    torch.cuda.synchronize()
+    env.step_device(tape[200 + rep])
+    torch.cuda.synchronize()
+    b = buf.cpu().numpy().astype(np.int64)
+    t0 = b[:, 0].min()
+    us = (b[:, :7] - t0) / 100.0
+    flag = b[:, 7]
+    for cls, sel in (("all", np.ones(n, bool)), ("fast", flag == 0), ("eat", (flag & 1) == 1), ("done", (flag & 2) == 2)):
+        if sel.sum() == 0:
+            continue
+        acc.setdefault(cls, []).append(np.stack([us[sel].min(0), np.median(us[sel], 0), us[sel].max(0)]))
+        acc.setdefault(cls + "_n", []).append(sel.sum())
+for cls in ("all", "fast", "eat", "done"):
+    if cls not in acc:
+        continue
+    m = np.mean(acc[cls], 0)
+    print(f"--- {cls} waves (avg {np.mean(acc[cls + '_n']):.0f} of {n}): min / median / max us since first wave start")
+    for i, nm in enumerate(names):
+        print(f"  {nm:14s} {m[0, i]:6.2f} {m[1, i]:6.2f} {m[2, i]:6.2f}")
