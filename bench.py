@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--python-loop", action="store_true", help="issue launches from Python instead of msnake_step_tape")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the secondary msnake_rollout_tape leg (profiling)")
     args = ap.parse_args()
 
     import torch
@@ -149,7 +150,7 @@ def main():
     # chunk, env state kept in registers across steps).  Only usable when the actions of several
     # steps exist up front, so it is reported beside the headline, not as it.
     rollout = None
-    if rank == 0 and not args.python_loop:
+    if rank == 0 and not args.python_loop and not args.no_rollout:
         def run_rollout(nsteps):
             k = 0
             while k < nsteps:
