@@ -51,9 +51,16 @@ def cpu_baseline(actions_host, seconds=12.0):
         el = time.perf_counter() - t0
         if el >= seconds or k >= 200000:
             break
+    # the same port on ONE core (a short sample), so the per-core rate is on record too
+    t1 = time.perf_counter()
+    k1 = 0
+    while time.perf_counter() - t1 < 2.0:
+        ora.step(actions_host[k1 % len(actions_host)], threads=1)
+        k1 += 1
+    one = n * k1 / (time.perf_counter() - t1)
     return {"value": round(n * k / el, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{k} lockstep steps of {n} envs (19x19, 3 snakes, obs render included) in {el:.1f}s, "
-                      f"OpenMP over env ranges"}
+                      f"OpenMP over env ranges", "one_core_value": round(one, 1)}
 
 
 def load_pmc_traffic():

@@ -283,6 +283,23 @@ def test_rollout_tape_with_bodies_longer_than_one_chunk():
     env.close()
 
 
+def test_step_without_observation_buffer():
+    """obs_dev = NULL skips the render; everything else is unchanged."""
+    import torch
+    import msnake
+    a = _mk(num_envs=300, dim=19, n_snakes=3, rules="snake_env", seed=2)
+    b = _mk(num_envs=300, dim=19, n_snakes=3, rules="snake_env", seed=2)
+    a.reset(); b.reset()
+    acts = torch.randint(0, 5, (30, 300, 3), dtype=torch.int32, device=a.device)
+    for t in range(30):
+        msnake._capi.check(a._L.msnake_step(a._h, acts[t].data_ptr(), 3, None, a._rew.data_ptr(), a._done.data_ptr(),
+                                            a._info.data_ptr(), a._stream()))
+        _, r, d, i = b.step_device(acts[t])
+        assert torch.equal(a._rew, r) and torch.equal(a._done, d) and torch.equal(a._info, i)
+    assert np.array_equal(a.render(), b.render())
+    a.close(); b.close()
+
+
 def test_errors_are_exceptions():
     import torch
     with pytest.raises(RuntimeError, match="n_snakes"):
