@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--python-loop", action="store_true", help="issue launches from Python instead of msnake_step_tape")
     ap.add_argument("--no-rollout", action="store_true", help="skip the secondary msnake_rollout_tape leg (profiling)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + MSNAKE_BENCH_ONE_DEVICE=1 rehearses the N>1 path with every rank on cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -95,8 +97,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("MSNAKE_BENCH_ONE_DEVICE") == "1":
+            local_rank = 0  # rehearsal on a one-GPU box: all ranks share the card (RCCL refuses that, use gloo)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -176,9 +183,10 @@ def main():
         rollout = r0.elapsed_time(r1) * 1e3 / K  # us per step
         env.stats(reset=True)
     # the only collective of the path: all-gather of the per-rank episode statistics (RCCL)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # collectives run where the backend lives
     rec = torch.tensor([st["episodes"], st["ep_len_sum"], st["ep_return_sum"], st["env_steps"]],
-                       dtype=torch.int64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                       dtype=torch.int64, device=cdev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if dist:
         allrec = [torch.zeros_like(rec) for _ in range(world)]
         dist.all_gather(allrec, rec)
