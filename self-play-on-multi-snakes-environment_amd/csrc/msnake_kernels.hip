@@ -113,7 +113,8 @@ __device__ __forceinline__ bool in_grid(uint32_t cell, int dim) {
 
 typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
 
-// MODE 0: step, 1: reset every env (msnake_reset), 2: render only (msnake_render)
+// MODE 0: step, 1: reset every env (msnake_reset), 2: render only (msnake_render), 3: n_steps steps of
+//      an action tape in ONE launch with the env kept in registers (msnake_rollout_tape)
 // K: integer pixel replication of the observation fused into the copy-out (the reference's WarpFrame,
 //    src/utils.py:15-31: cv2.resize to 84x84 with INTER_AREA, which for the exact integer up-scales
 //    used there -- 21->84 = x4, 12->84 = x7 -- is plain pixel replication)

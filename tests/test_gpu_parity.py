@@ -335,3 +335,41 @@ def test_selfplay_ppo_rollouts_end_to_end():
     assert st["env_steps"] == 256 * 16 * 3 and st["errors"] == 0 and st["episodes"] > 0
     assert next(model.parameters()).is_cuda
     env.close()
+
+
+def test_vecenv_surface_like_the_reference_runner_uses_it():
+    """ppo_multi_agent.Runner's view of the env (src/ppo_multi_agent.py:145-216): attributes, tuple
+    actions of length 2/3 even with fewer snakes, NumPy returns, info dicts, reset/close."""
+    import msnake
+    env = msnake.make("snake-multiple-test-v0", 33, n_snakes=1, seed=4)
+    assert env.num_envs == 33 and env.action_space.n == 5
+    assert env.observation_space.shape == (21, 21, 6) and env.obs_shape == (21, 21, 9)
+    assert env.unwrapped is env and env.rules == "snake_env"
+    obs = env.reset()
+    assert obs.dtype == np.uint8 and obs.shape == (33, 21, 21, 9)
+    full_actions = list(zip([1] * 33, [1] * 33))  # MultiModel.multi_step with one snake: tuples of 2
+    obs2, rews, dones, infos = env.step(full_actions)
+    assert rews.dtype == np.float32 and dones.dtype == np.bool_ and len(infos) == 33
+    assert (1.0 - dones).shape == (33,)  # ppo_multi_agent.py:207
+    assert all(set(i) >= {"ale.lives", "num_snakes"} for i in infos)
+    with pytest.raises(RuntimeError):
+        env.step_wait()  # no step_async pending
+    env.step_async(full_actions)
+    env.step_wait()
+    total_done = 0
+    for _ in range(40):
+        _, _, dones, infos = env.step(full_actions)
+        total_done += int(dones.sum())
+        for d, i in zip(dones, infos):
+            assert ("episode" in i) == bool(d)
+            if d:
+                assert set(i["episode"]) == {"r", "l", "t"} and i["episode"]["l"] >= 1
+    st = env.stats(reset=True)
+    assert st["episodes"] >= total_done > 0 and st["env_steps"] == 33 * 42
+    assert env.stats()["episodes"] == 0 and env.stats()["env_steps"] == 0
+    assert np.array_equal(env.render(), env._obs.cpu().numpy())
+    env.close(); env.close()
+    for env_id, shape in (("snake-new-multiple-v0", (12, 12, 6)), ("snake-adversarial-v0", (12, 12, 9))):
+        e2 = msnake.make(env_id, 8, n_snakes=2)
+        assert e2.obs_shape == shape and e2.reset().shape == (8,) + shape
+        e2.close()
