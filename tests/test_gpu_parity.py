@@ -373,3 +373,51 @@ def test_vecenv_surface_like_the_reference_runner_uses_it():
         e2 = msnake.make(env_id, 8, n_snakes=2)
         assert e2.obs_shape == shape and e2.reset().shape == (8,) + shape
         e2.close()
+
+
+def _serpentine(dim, length, start_row, rs):
+    """A self-avoiding boustrophedon body of `length` cells starting in row `start_row` (head last
+    visited, i.e. head first in the list), so bodies far longer than one 64-cell chunk are legal."""
+    path = []
+    for r in range(start_row, dim):
+        cols = range(dim) if (r - start_row) % 2 == 0 else range(dim - 1, -1, -1)
+        path += [[c, r] for c in cols]
+    path = path[:length]
+    return path[::-1]
+
+
+@pytest.mark.parametrize("rules", ["snake_env", "new_world", "adversarial"])
+def test_fuzz_long_bodies_against_oracle(rules):
+    """Hand-built states with bodies of 50..250 cells (up to 4 chunks of 64): the ring path of the
+    collision scan, the respawn occupancy and the painter, which random play almost never reaches."""
+    from oracle.snake_oracle import Oracle
+    rs = np.random.default_rng(99)
+    dim, n, ns = 19, 96, 2
+    nf = 2 if rules != "new_world" else 3
+    env = _mk(num_envs=n, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=13)
+    ora = Oracle(n, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=13)
+    env.reset(); ora.reset()
+    for e in range(n):
+        la, lb = int(rs.integers(50, 250)), int(rs.integers(1, 60))
+        a = _serpentine(dim, la, 0, rs)
+        b = _serpentine(dim, lb, 15, rs)
+        # head of a is at the end of its last (partial) row, moving along that row
+        hr = a[0][1]
+        va = [1, 0] if (hr % 2 == 0) else [-1, 0]
+        st = {"snakes": [a, b], "fruits": [[int(rs.integers(0, dim)), int(rs.integers(0, dim))] for _ in range(nf)],
+              "vels": [va, [0, 0]], "grow_to": [la + int(rs.integers(0, 3)), lb + 2], "t": int(rs.integers(0, 100)),
+              "ctr": int(rs.integers(0, 1000)), "alive": [True, True], "in_dead": [False, False], "spare_fruits": int(rs.integers(0, 3))}
+        _set_state(env, e, st); ora.set_state(e, st)
+    assert np.array_equal(env.render(), ora.render())
+    for t in range(40):
+        act = rs.integers(0, 5, (n, ns)).astype(np.int32)
+        act[:, 0] = np.where(rs.random(n) < 0.8, 0, act[:, 0])  # mostly keep going so the long snake survives a while
+        obs, rew, done, infos = env.step(act)
+        o_obs, o_rew, o_done, o_ns, o_er, o_el = ora.step(act)
+        assert np.array_equal(rew, o_rew) and np.array_equal(done, o_done.astype(bool)), t
+        assert np.array_equal(infos._ns, o_ns) and np.array_equal(infos._l, o_el), t
+        assert np.array_equal(obs, o_obs), t
+    for e in range(0, n, 7):
+        assert _state(env, e) == ora.get_state(e), e
+    assert env.stats()["errors"] == 0
+    env.close()
