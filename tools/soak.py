@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Long parity soak on the GPU box: N envs x T steps, HIP env vs CPU oracle on the same actions.
+rew/done/info every step, observation every `--obs-every` steps, full state at the end."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--dim", type=int, default=19)
+    ap.add_argument("--snakes", type=int, default=3)
+    ap.add_argument("--fruits", type=int, default=None)
+    ap.add_argument("--rules", default="snake_env")
+    ap.add_argument("--keep", type=float, default=0.6, help="probability of action 0 (snakes live longer)")
+    ap.add_argument("--obs-every", type=int, default=25)
+    ap.add_argument("--max-steps", type=int, default=2000)
+    args = ap.parse_args()
+    import torch
+    import msnake
+    from oracle.snake_oracle import Oracle
+
+    n, ns = args.envs, args.snakes
+    env = msnake.MultiSnakeVecEnv(n, dim=args.dim, n_snakes=ns, n_fruits=args.fruits, rules=args.rules, seed=77,
+                                  max_steps=args.max_steps)
+    ora = Oracle(n, dim=args.dim, n_snakes=ns, n_fruits=args.fruits, rules=args.rules, seed=77, max_steps=args.max_steps)
+    assert np.array_equal(env.reset(), ora.reset())
+    rs = np.random.default_rng(5)
+    t0 = time.time()
+    episodes = maxlen = 0
+    for t in range(args.steps):
+        act = rs.integers(0, 5, (n, ns)).astype(np.int32)
+        act = np.where(rs.random((n, ns)) < args.keep, 0, act).astype(np.int32)
+        obs_d, rew, done, info = env.step_device(torch.from_numpy(act).to(env.device))
+        want_obs = t % args.obs_every == 0 or t == args.steps - 1
+        o_obs, o_rew, o_done, o_ns, o_er, o_el = ora.step(act, threads=16, want_obs=want_obs)
+        info_h = info.cpu().numpy()
+        assert np.array_equal(rew.cpu().numpy(), o_rew), t
+        assert np.array_equal(done.cpu().numpy(), o_done), t
+        assert np.array_equal(info_h[:, 2], o_ns) and np.array_equal(info_h[:, 1], o_el), t
+        assert np.array_equal(info_h[:, 0].copy().view(np.float32), o_er), t
+        if want_obs:
+            assert np.array_equal(obs_d.cpu().numpy(), o_obs), t
+        episodes += int(o_done.sum())
+        if t % 500 == 0:
+            print(f"step {t}: ok, episodes so far {episodes}, {time.time() - t0:.0f}s", flush=True)
+    from oracle.snake_oracle import flat_to_state
+    for e in range(0, n, max(1, n // 256)):
+        st = flat_to_state(env.get_state_words(e))
+        assert st == ora.get_state(e), e
+        maxlen = max(maxlen, max(len(b) for b in st["snakes"]))
+    st = env.stats()
+    assert st["errors"] == 0 and st["episodes"] == episodes
+    print(f"SOAK OK: {args.rules} {n} envs x {args.steps} steps, {episodes} episodes, "
+          f"longest body at the end {maxlen}, {time.time() - t0:.0f}s")
+
+
+if __name__ == "__main__":
+    main()
