@@ -40,6 +40,14 @@ void run(const char* tag, int blocks, int threads, size_t lds, int spin) {
 }
 
 int main() {
+    run<1>("VGPR sweep: 1", 1024, 256, 0, 2);
+    run<8>("VGPR sweep: 8", 1024, 256, 0, 2);
+    run<16>("VGPR sweep: 16", 1024, 256, 0, 2);
+    run<24>("VGPR sweep: 24", 1024, 256, 0, 2);
+    run<32>("VGPR sweep: 32", 1024, 256, 0, 2);
+    run<48>("VGPR sweep: 48", 1024, 256, 0, 2);
+    run<64>("VGPR sweep: 64", 1024, 256, 0, 2);
+    run<96>("VGPR sweep: 96", 1024, 256, 0, 2);
     run<1>("trivial, 1024 x 256 thr", 1024, 256, 0, 0);
     run<1>("trivial + 17.8 KB LDS, 1024 x 256", 1024, 256, 17856, 0);
     run<1>("trivial, 4096 x 64 thr", 4096, 64, 0, 0);
