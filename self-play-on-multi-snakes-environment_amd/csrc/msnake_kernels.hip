@@ -190,18 +190,19 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     //      only; `draws` caches the u32 of draws [draw_base, draw_base + 64) --------------------
     uint32_t draws = 0, draw_base = 0;
     bool draws_valid = false;
+    auto refill_draws = [&](uint32_t ctr_lo, uint32_t ctr_hi) {
+        const uint64_t gid = p.env_id_base + (uint64_t)e;
+        uint32_t k0 = p.seed_lo, k1 = p.seed_hi;
+        // slow path only: keep the ten-round key schedule from being hoisted to kernel entry,
+        // where it would pin 20 SGPRs for every wave
+        asm volatile("" : "+s"(k0), "+s"(k1));
+        draws = philox_draws(ctr_lo, ctr_hi, lane, (uint32_t)gid, (uint32_t)(gid >> 32), k0, k1);
+        draw_base = ctr_lo; draws_valid = true;
+    };
     auto randint = [&](uint32_t n) -> uint32_t {
         const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
         uint32_t idx = ctr_lo - draw_base;
-        if (!draws_valid || idx >= 64u) {
-            const uint64_t gid = p.env_id_base + (uint64_t)e;
-            uint32_t k0 = p.seed_lo, k1 = p.seed_hi;
-            // slow path only: keep the ten-round key schedule from being hoisted to kernel entry,
-            // where it would pin 20 SGPRs for every wave
-            asm volatile("" : "+s"(k0), "+s"(k1));
-            draws = philox_draws(ctr_lo, ctr_hi, lane, (uint32_t)gid, (uint32_t)(gid >> 32), k0, k1);
-            draw_base = ctr_lo; draws_valid = true; idx = 0;
-        }
+        if (!draws_valid || idx >= 64u) { refill_draws(ctr_lo, ctr_hi); idx = 0; }
         const uint32_t u = rdlane(draws, (int)idx);
         const uint32_t nlo = ctr_lo + 1;
         HV_SET(HDR_CTR_LO, nlo);
@@ -295,23 +296,42 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #pragma unroll
             for (int s = 0; s < NS; ++s) HV_SET(SN_A(s), 0u);
         }
+        if (RULES != MSNAKE_RULES_NEW_WORLD) {
+            // [S]:223-225 draws snake s's cell then fruit s's cell, each (randint(dim), randint(dim)):
+            // 4*NS consecutive draws.  All of them at once: lane l takes draw ctr + l.
+            const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
+            uint32_t idx0 = ctr_lo - draw_base;
+            if (!draws_valid || idx0 + 4u * NS > 64u) { refill_draws(ctr_lo, ctr_hi); idx0 = 0; }
+            const uint32_t u = (uint32_t)__shfl((int)draws, (int)idx0 + lane);
+            const uint32_t v = (uint32_t)(((uint64_t)u * (uint32_t)dim) >> 32) + 1u;  // padded coordinate
+            const uint32_t cellv = (v << 8) | row_shl<1>(0u, v);                     // even lanes: (c0+1, c1+1)
+            hv = lane < NS ? (1u << 16) : hv;                    // SN_A: head_pos 0, len 1
+            hv = (lane >= 4 && lane < 4 + NS) ? 3u : hv;         // SN_B: grow_to 3
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const uint32_t c0 = randint((uint32_t)dim), c1 = randint((uint32_t)dim);
-            const uint32_t hd = ((c0 + 1) << 8) | (c1 + 1);
-            HV_SET(SN_A(s), 1u << 16);   // head_pos 0, len 1
-            HV_SET(SN_B(s), 3u);     // grow_to 3
-            HV_SET(SN_C(s), hd);     // head cell, velocity (0,0)
-            cr[s] = hd;
-            if (lane == 0) ring_g[(size_t)s * cap] = (uint16_t)hd;
-            if (RULES != MSNAKE_RULES_NEW_WORLD) {  // snake cell, then its fruit, unconstrained
-                const uint32_t f0 = randint((uint32_t)dim), f1 = randint((uint32_t)dim);
-                const uint32_t fc = ((f0 + 1) << 8) | (f1 + 1);
+            for (int s = 0; s < NS; ++s) {
+                const uint32_t hd = rdlane(cellv, 4 * s), fc = rdlane(cellv, 4 * s + 2);
+                HV_SET(SN_C(s), hd);  // head cell, velocity (0,0)
+                cr[s] = hd;
+                if (lane == 0) ring_g[(size_t)s * cap] = (uint16_t)hd;
                 if (RULES == MSNAKE_RULES_ADVERSARIAL) {  // fruits = [] then append ([A]:224-229)
                     if (lane == s) { fr = fc; flist_g[s] = (uint16_t)fc; }
                 } else {
                     HV_SET(HDR_FRUIT0 + s, fc);
                 }
+            }
+            const uint32_t nlo = ctr_lo + 4u * NS;
+            HV_SET(HDR_CTR_LO, nlo);
+            if (nlo < ctr_lo) { HV_SET(HDR_CTR_HI, ctr_hi + 1); draws_valid = false; }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const uint32_t c0 = randint((uint32_t)dim), c1 = randint((uint32_t)dim);
+                const uint32_t hd = ((c0 + 1) << 8) | (c1 + 1);
+                HV_SET(SN_A(s), 1u << 16);   // head_pos 0, len 1
+                HV_SET(SN_B(s), 3u);         // grow_to 3
+                HV_SET(SN_C(s), hd);         // head cell, velocity (0,0)
+                cr[s] = hd;
+                if (lane == 0) ring_g[(size_t)s * cap] = (uint16_t)hd;
             }
         }
         if (RULES == MSNAKE_RULES_NEW_WORLD) {  // all snakes first, then n_fruits safe cells
