@@ -222,14 +222,15 @@ def test_step_tape_equals_single_steps():
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("rules,dim,ns,nf", [("snake_env", 19, 3, 3), ("new_world", 10, 2, 4), ("adversarial", 10, 3, 3)])
-def test_rollout_tape_persistent_launch_equals_single_steps(rules, dim, ns, nf):
+@pytest.mark.parametrize("rules,dim,ns,nf,scale", [("snake_env", 19, 3, 3, 1), ("new_world", 10, 2, 4, 1),
+                                                   ("adversarial", 10, 3, 3, 1), ("snake_env", 19, 2, 2, 4)])
+def test_rollout_tape_persistent_launch_equals_single_steps(rules, dim, ns, nf, scale):
     """msnake_rollout_tape (one persistent launch for T steps) == T msnake_step launches."""
     import torch
     import msnake
-    n, T = 777, 48
-    a = _mk(num_envs=n, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=21)
-    b = _mk(num_envs=n, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=21)
+    n, T = (777, 48) if scale == 1 else (150, 12)
+    a = _mk(num_envs=n, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=21, obs_scale=scale)
+    b = _mk(num_envs=n, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=21, obs_scale=scale)
     a.reset(); b.reset()
     tape = torch.randint(0, 5, (T, n, ns), dtype=torch.int32, device=a.device)
     H, W, C = a.obs_shape
