@@ -83,17 +83,19 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t philox_draws(uint32_t base_lo, uint32_t base_hi, int lane, uint32_t g_lo,
                                                  uint32_t g_hi, uint32_t k0, uint32_t k1) {
-    const uint64_t d = (((uint64_t)base_hi << 32) | base_lo) + (uint64_t)lane;
-    uint32_t c0 = (uint32_t)(d >> 2), c1 = (uint32_t)(d >> 34), c2 = g_lo, c3 = g_hi;
+    const uint32_t d_lo = base_lo + (uint32_t)lane;              // draw index of this lane, 64 bit
+    const uint32_t d_hi = base_hi + (d_lo < base_lo ? 1u : 0u);
+    uint32_t c0 = (d_lo >> 2) | (d_hi << 30), c1 = d_hi >> 2, c2 = g_lo, c3 = g_hi;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        const uint32_t n0 = __umulhi(0xCD9E8D57u, c2) ^ c1 ^ k0;
+        c1 = 0xCD9E8D57u * c2;
+        const uint32_t n2 = __umulhi(0xD2511F53u, c0) ^ c3 ^ k1;
+        c3 = 0xD2511F53u * c0;
+        c0 = n0; c2 = n2;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    const uint32_t sel = (uint32_t)d & 3u;
+    const uint32_t sel = d_lo & 3u;
     return sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
 }
 
