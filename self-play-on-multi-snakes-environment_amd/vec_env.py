@@ -87,7 +87,7 @@ class MultiSnakeVecEnv:
 
     def __init__(self, num_envs, dim=19, n_snakes=3, n_fruits=None, rules="snake_env", seed=0,
                  env_id_base=0, device=None, max_steps=2000, auto_reset=True, obs_scale=1,
-                 declared_channels=6):
+                 declared_channels=6, host_views=False):
         import torch  # device memory and streams only
 
         if not torch.cuda.is_available():
@@ -121,6 +121,15 @@ class MultiSnakeVecEnv:
             self._rew = torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)
             self._done = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
             self._info = torch.zeros((self.num_envs, 4), dtype=torch.int32, device=self.device)
+        # NumPy-returning calls copy device -> host.  Default: fresh arrays every call, like the
+        # reference's np.stack (pageable copy, ~10 GB/s).  host_views=True returns views of pinned
+        # staging buffers instead (~5x faster, but OVERWRITTEN by the next call: copy what you keep,
+        # as ppo_multi_agent.py:165-168 does anyway).
+        self._host_views = bool(host_views)
+        self._pinned = None
+        if self._host_views:
+            pin = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self._pinned = (pin(self._obs), pin(self._rew), pin(self._done), pin(self._info))
         self._pending = None
         self._tstart = time.time()
         self.closed = False
@@ -155,9 +164,16 @@ class MultiSnakeVecEnv:
         return obs
 
     # ------------------------------------------------------------------ VecEnv surface (NumPy out)
+    def _obs_to_host(self, obs):
+        if not self._host_views:
+            return obs.cpu().numpy()
+        self._pinned[0].copy_(obs, non_blocking=True)
+        self._torch.cuda.current_stream(self.device).synchronize()
+        return self._pinned[0].numpy()
+
     def reset(self):
         self._tstart = time.time()
-        return self.reset_device().cpu().numpy()
+        return self._obs_to_host(self.reset_device())
 
     def step_async(self, actions):
         torch = self._torch
@@ -172,18 +188,24 @@ class MultiSnakeVecEnv:
             raise RuntimeError("step_wait() called without step_async()")  # NotSteppingError in baselines
         obs, rew, done, info = self._pending
         self._pending = None
-        info_h = info.cpu().numpy()
-        done_h = done.cpu().numpy().astype(bool)
-        infos = LazyInfos(done_h, info_h[:, 2], info_h[:, 0].copy().view(np.float32), info_h[:, 1],
+        if self._host_views:
+            for dst, src in zip(self._pinned, (obs, rew, done, info)):
+                dst.copy_(src, non_blocking=True)
+            self._torch.cuda.current_stream(self.device).synchronize()
+            obs_h, rew_h, done_u8, info_h = (t.numpy() for t in self._pinned)
+        else:
+            obs_h, rew_h, done_u8, info_h = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), info.cpu().numpy()
+        done_h = done_u8.astype(bool)
+        infos = LazyInfos(done_h, info_h[:, 2].copy(), info_h[:, 0].copy().view(np.float32), info_h[:, 1].copy(),
                           round(time.time() - self._tstart, 6))
-        return obs.cpu().numpy(), rew.cpu().numpy(), done_h, infos
+        return obs_h, rew_h, done_h, infos
 
     def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
 
     def render(self, mode="rgb_array"):
-        return self.render_device().cpu().numpy()
+        return self.render_device().cpu().numpy()  # always a fresh array
 
     def close(self):
         if not self.closed and self._h:

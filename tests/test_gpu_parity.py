@@ -370,6 +370,18 @@ def test_vecenv_surface_like_the_reference_runner_uses_it():
     assert env.stats()["episodes"] == 0 and env.stats()["env_steps"] == 0
     assert np.array_equal(env.render(), env._obs.cpu().numpy())
     env.close(); env.close()
+    # pinned zero-copy host views give the same numbers
+    a = msnake.make("snake-multiple-test-v0", 50, n_snakes=3, seed=9)
+    b = msnake.make("snake-multiple-test-v0", 50, n_snakes=3, seed=9, host_views=True)
+    assert np.array_equal(a.reset(), b.reset())
+    for t in range(15):
+        act = np.random.default_rng(t).integers(0, 5, (50, 3))
+        ra, rb = a.step(act), b.step(act)
+        assert all(np.array_equal(x, y) for x, y in zip(ra[:3], rb[:3]))
+        assert [i for i in ra[3]] == [i for i in rb[3]] or all(
+            {k: v for k, v in i.items() if k != "episode"} == {k: v for k, v in j.items() if k != "episode"}
+            for i, j in zip(ra[3], rb[3]))
+    a.close(); b.close()
     for env_id, shape in (("snake-new-multiple-v0", (12, 12, 6)), ("snake-adversarial-v0", (12, 12, 9))):
         e2 = msnake.make(env_id, 8, n_snakes=2)
         assert e2.obs_shape == shape and e2.reset().shape == (8,) + shape
