@@ -48,6 +48,7 @@ def lib():
         L.orc_render.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.orc_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_void_p] * 6
         L.orc_step_mt.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_void_p] * 6
+        L.orc_rollout_mt.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 6
         L.orc_max_threads.restype = ctypes.c_int
         L.orc_export_state.restype = ctypes.c_int32
         L.orc_export_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int32]
@@ -163,6 +164,15 @@ class Oracle:
             self.L.orc_step_mt(self.h, threads, *args)
         else:
             self.L.orc_step(self.h, *args)
+        return self.obs, self.rew, self.done, self.num_snakes, self.ep_return, self.ep_len
+
+    def rollout(self, tape, threads):
+        """T lockstep steps of tape int32 [T, num_envs, stride] with one persistent thread team."""
+        a = np.ascontiguousarray(tape, dtype=np.int32)
+        assert a.ndim == 3 and a.shape[1] == self.num_envs and a.shape[2] >= self.n_snakes
+        self.L.orc_rollout_mt(self.h, threads, a.ctypes.data, a.shape[2], a.shape[0], self.obs.ctypes.data,
+                              self.rew.ctypes.data, self.done.ctypes.data, self.num_snakes.ctypes.data,
+                              self.ep_return.ctypes.data, self.ep_len.ctypes.data)
         return self.obs, self.rew, self.done, self.num_snakes, self.ep_return, self.ep_len
 
     def get_state(self, env):
