@@ -161,7 +161,7 @@ def test_ragged_batch_sizes_and_unaligned_images(num_envs):
 
 @pytest.mark.parametrize("dim,n_snakes,rules,scale", [(19, 3, "snake_env", 4), (10, 1, "snake_env", 7),
                                                       (10, 2, "new_world", 7), (10, 2, "adversarial", 7),
-                                                      (19, 2, "snake_env", 4)])
+                                                      (19, 2, "snake_env", 4), (19, 4, "new_world", 4)])
 def test_fused_warpframe_is_pixel_replication(dim, n_snakes, rules, scale):
     """obs_scale = the reference's WarpFrame (src/utils.py:15-31): 84x84 frames.  cv2 is not
     installed, so parity with cv2.resize(INTER_AREA) is UNPINNED; the contract tested here is exact
@@ -434,3 +434,13 @@ def test_fuzz_long_bodies_against_oracle(rules):
         assert _state(env, e) == ora.get_state(e), e
     assert env.stats()["errors"] == 0
     env.close()
+
+
+@pytest.mark.parametrize("dim,ns,nf,rules", [(2, 1, 1, "snake_env"), (3, 2, 2, "snake_env"), (5, 3, 3, "adversarial"),
+                                              (30, 3, 3, "snake_env"), (62, 3, 3, "snake_env"), (62, 4, 32, "new_world"),
+                                              (45, 4, 0, "new_world"), (7, 1, 9, "new_world")])
+def test_unusual_grid_sizes(dim, ns, nf, rules):
+    """Grid sizes from 2x2 to the 62x62 maximum (LDS image up to 48 KB: one env per workgroup),
+    fruit counts 0..32, against the oracle."""
+    n = 37
+    _run_vs_oracle(n, dim, ns, nf, rules, 60, seed=31, greedy=0.5)
