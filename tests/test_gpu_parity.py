@@ -444,3 +444,30 @@ def test_unusual_grid_sizes(dim, ns, nf, rules):
     fruit counts 0..32, against the oracle."""
     n = 37
     _run_vs_oracle(n, dim, ns, nf, rules, 60, seed=31, greedy=0.5)
+
+
+def test_step_is_hip_graph_capturable():
+    """msnake_step does no allocation, copy or synchronisation, so a caller can capture it (with
+    its policy) into a HIP graph; replays must equal direct launches."""
+    import torch
+    n = 512
+    a = _mk(num_envs=n, dim=19, n_snakes=3, rules="snake_env", seed=17)
+    b = _mk(num_envs=n, dim=19, n_snakes=3, rules="snake_env", seed=17)
+    a.reset(); b.reset()
+    acts = torch.zeros((n, 3), dtype=torch.int32, device=a.device)
+    tape = torch.randint(0, 5, (25, n, 3), dtype=torch.int32, device=a.device)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # warm-up on the side stream, as graph capture wants
+        a.step_device(acts); b.step_device(acts)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        a.step_device(acts)
+    # the capture itself did not execute the step
+    for t in range(25):
+        acts.copy_(tape[t])
+        g.replay()
+        o, r, d, i = b.step_device(tape[t])
+        assert torch.equal(a._obs, o) and torch.equal(a._rew, r) and torch.equal(a._done, d) and torch.equal(a._info, i), t
+    a.close(); b.close()
