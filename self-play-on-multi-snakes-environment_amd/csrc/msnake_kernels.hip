@@ -255,18 +255,27 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     uint64_t freemask = 0;   // lane c: free cells of chunk c
     uint32_t freescan = 0;   // lane c: number of free cells in chunks 0..c
     int nfree = 0;
+    // [S] respawns run AHEAD of the vector move (section 1a): snakes in `bf_moved` count as already
+    // moved, i.e. without their popped tail (lane j of bf_pop) and with their new head (bf_nh).
+    uint32_t bf_moved = 0, bf_pop = 0, bf_nh = 0;
     auto build_free = [&]() {
         uint32_t* occw = reinterpret_cast<uint32_t*>(occ);
         for (int i = lane; i < ((n2 + 63) >> 6) * 2; i += 64) occw[i] = 0u;  // one bit per cell
         wave_sync();
+        auto mark = [&](int, uint32_t cell) {
+            // used = c1*dim + c0; out-of-grid heads alias onto other cells or fall outside
+            const int used = ((int)(cell & 255u) - 1) * dim + ((int)(cell >> 8) - 1);
+            if ((uint32_t)used < (uint32_t)n2) atomicOr(&occw[used >> 5], 1u << (used & 31));
+        };
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const uint32_t w0 = rdlane(hv, SN_A(j));
-            for_each_piece(j, cr[j], (int)(w0 & 0xFFFFu), (int)(w0 >> 16), [&](int, uint32_t cell) {
-                // used = c1*dim + c0; out-of-grid heads alias onto other cells or fall outside
-                const int used = ((int)(cell & 255u) - 1) * dim + ((int)(cell >> 8) - 1);
-                if ((uint32_t)used < (uint32_t)n2) atomicOr(&occw[used >> 5], 1u << (used & 31));
-            });
+            int len = (int)(w0 >> 16);
+            if (RULES == MSNAKE_RULES_SNAKE_ENV && ((bf_moved >> j) & 1u)) {
+                len -= (int)rdlane(bf_pop, j);
+                if (lane == 0) mark(0, rdlane(bf_nh, j));
+            }
+            for_each_piece(j, cr[j], (int)(w0 & 0xFFFFu), len, mark);
         }
         wave_sync();
         const int base = lane * 64;
@@ -414,21 +423,54 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             for (int f = 0; f < nf; ++f)
                 v_em |= ((uint32_t)v_nh == (rdlane(hv, HDR_FRUIT0 + f) & 0xFFFFu)) ? (1u << f) : 0u;
         }
+        v_em = v_moves ? v_em : 0u;
         STAMP(1);
         const uint64_t mvmask = ballot(v_moves);
-        bool any_eat = ballot(v_moves && v_em != 0) != 0;
+        bool any_eat = ballot(v_em != 0) != 0;
         if (RULES == MSNAKE_RULES_ADVERSARIAL) {
 #pragma unroll
             for (int s = 0; s < NS; ++s)
                 if (((mvmask >> s) & 1ull) && fruits_on(rdlane((uint32_t)v_nh, s)) != 0) any_eat = true;
         }
-        if (!any_eat) {
+        if (RULES == MSNAKE_RULES_SNAKE_ENV && any_eat) {
+            // ---- 1a. [S] respawns, in snake order, ahead of the vector move.  update_snake
+            //      ([S]:119-141) pops, inserts the head and only then re-places the fruits it ate, so
+            //      snake s's respawns see snakes <= s moved and snakes > s unmoved; a fruit that lands
+            //      on a later snake's new head is eaten by it in this very step ([S]:126-132 runs on
+            //      the current fruit positions), which is what re-deriving bit f of the later lanes'
+            //      eat masks reproduces.
+            bf_nh = (uint32_t)v_nh;
+#pragma nounroll
+            for (int s = 0; s < NS; ++s) {
+                uint32_t m = rdlane(v_em, s);
+                if (m == 0) continue;
+                bf_pop = (v_moves && v_len >= v_grow + 2 * __builtin_popcount(v_em)) ? 1u : 0u;  // lanes <= s are final
+                bf_moved = (uint32_t)mvmask & ((2u << s) - 1u);
+                build_free();
+                while (m) {
+                    const int f = __builtin_ffs((int)m) - 1;
+                    m &= m - 1;
+                    const uint32_t c = safe_cell();
+                    HV_SET(HDR_FRUIT0 + f, c);
+                    const uint32_t bit = (uint32_t)v_nh == c ? (1u << f) : 0u;
+                    v_em = (v_moves && lane > s) ? ((v_em & ~(1u << f)) | bit) : v_em;
+                }
+            }
+            bf_moved = 0;
+        }
+        if (RULES == MSNAKE_RULES_SNAKE_ENV || !any_eat) {
             int pops;
+            uint32_t nB = (uint32_t)v_grow;
             if (RULES == MSNAKE_RULES_NEW_WORLD) {  // [N]:143-150 runs the pop test once per fruit
                 pops = v_len - v_grow + 1;
                 pops = pops < 0 ? 0 : (pops > nf ? nf : pops);
+            } else if (RULES == MSNAKE_RULES_SNAKE_ENV) {
+                const int neat = __builtin_popcount(v_em);
+                nB = (uint32_t)(v_grow + 2 * neat);      // [S]:126-132
+                pops = v_len >= (int)nB ? 1 : 0;         // [S]:134-135
+                reward = (float)rdlane((uint32_t)neat, 0);
             } else {
-                pops = v_len >= v_grow ? 1 : 0;     // [S]:134-135
+                pops = v_len >= v_grow ? 1 : 0;     // [A]:134-135 (eating steps take the loop below)
             }
             int nlen = v_len - pops + 1;            // insert(0, head)
             if (ballot(v_moves && nlen > cap - 1) != 0) {  // unreachable under the documented caps
@@ -440,6 +482,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             const uint32_t nA = v_moves ? ((uint32_t)nhp | ((uint32_t)nlen << 16)) : sA;
             const uint32_t nC = v_moves ? ((uint32_t)v_nh | ((uint32_t)v_nvel << 16)) : sC;
             hv = lane < NS ? nA : hv;
+            if (RULES == MSNAKE_RULES_SNAKE_ENV) {
+                const uint32_t nB4 = row_shr<4>(hv, nB);
+                hv = (lane >= 4 && lane < 4 + NS) ? nB4 : hv;
+            }
             const uint32_t nC8 = row_shr<8>(hv, nC);
             hv = (lane >= 8 && lane < 8 + NS) ? nC8 : hv;
 #pragma unroll

@@ -569,6 +569,37 @@ def gen_edges():
     E.append(run_edge("S_invalid_action", S, 19, 3, 3,
                       S_state([[[5, 5]], [[9, 9]], [[0, 0]]], far, vels=[[1, 0], [0, 1], [0, 0]]),
                       [[7, -1, 5]], note="actions outside 1..4 keep the velocity"))
+    # --- [S] ordering between one snake's respawn and the other snakes' moves ([S]:119-141, 171-176)
+    E.append(run_edge("S_two_heads_one_fruit", S, 19, 3, 3,
+                      S_state([[[5, 5]], [[7, 5]], [[0, 0]]], [[6, 5], [18, 17], [17, 18]]), [[1, 3, 0]],
+                      note="both heads enter the fruit cell: only snake 0 eats (the fruit has moved on)"))
+    E.append(run_edge("S_opponents_share_fruit", S, 19, 3, 3,
+                      S_state([[[10, 10]], [[5, 5]], [[7, 5]]], [[18, 18], [6, 5], [17, 18]]),
+                      [[0, 1, 3], [0, 0, 0]],
+                      note="snakes 1 and 2 enter fruit 1's cell: snake 1 eats, both die, main plays on"))
+    # 3x3: the eater is at full length, so its popped tail cell (0,0) is free again for the respawn
+    for seed in range(64):
+        rec = run_edge("S_respawn_on_vacated_tail", S, 3, 1, 1,
+                       S_state([[[0, 2], [0, 1], [1, 1], [2, 1], [2, 0], [1, 0], [0, 0]]], [[1, 2]],
+                               vels=[[1, 0]], grow=[5]), [[0]], seed=seed, env_id=0,
+                       note="free cells after the move are the popped tail (0,0) and (2,2); lands on (0,0)")
+        if rec["steps"][0]["state"]["fruits"][0] == [0, 0]:
+            break
+    else:
+        raise SystemExit("no seed puts the fruit on the vacated tail")
+    E.append(rec)
+    # 3x3, two snakes: snake 0's respawn sees snake 1 UNMOVED (its tail (0,2) still there, its next
+    # head cell (2,1) still free); the fruit lands exactly on (2,1) and snake 1 eats it this step
+    for seed in range(256):
+        rec = run_edge("S_respawn_sees_later_unmoved", S, 3, 2, 2,
+                       S_state([[[0, 0]], [[2, 2], [1, 2], [0, 2]]], [[1, 0], [0, 0]],
+                               vels=[[1, 0], [0, -1]]), [[0, 0], [0, 0]], seed=seed, env_id=0,
+                       note="fruit 0 respawns on snake 1's next head cell and is eaten again at once")
+        if rec["steps"][0]["state"]["grow_to"][1] == 5:
+            break
+    else:
+        raise SystemExit("no seed puts the fruit on snake 1's next head cell")
+    E.append(rec)
     # --- [N] (A7-A10)
     E.append(run_edge("N_init_draws", N, 19, 3, 3,
                       N_state([[[5, 5]], [[9, 9]], [[0, 0]]], far), ["reset"],
