@@ -201,11 +201,15 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         draws = philox_draws(ctr_lo, ctr_hi, lane, (uint32_t)gid, (uint32_t)(gid >> 32), k0, k1);
         draw_base = ctr_lo; draws_valid = true;
     };
-    auto randint = [&](uint32_t n) -> uint32_t {
+    // the next `need` (<= 64) draws are cached afterwards.  Callers run this BEFORE they build
+    // their wide temporaries (free-cell masks), so Philox does not set the kernel's VGPR peak.
+    auto ensure_draws = [&](uint32_t need) {
         const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
-        uint32_t idx = ctr_lo - draw_base;
-        if (!draws_valid || idx >= 64u) { refill_draws(ctr_lo, ctr_hi); idx = 0; }
-        const uint32_t u = rdlane(draws, (int)idx);
+        if (!draws_valid || ctr_lo - draw_base > 64u - need) refill_draws(ctr_lo, ctr_hi);
+    };
+    auto randint = [&](uint32_t n) -> uint32_t {  // ensure_draws() has covered this draw
+        const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
+        const uint32_t u = rdlane(draws, (int)((ctr_lo - draw_base) & 63u));
         const uint32_t nlo = ctr_lo + 1;
         HV_SET(HDR_CTR_LO, nlo);
         if (nlo == 0) { HV_SET(HDR_CTR_HI, ctr_hi + 1); draws_valid = false; }
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     auto safe_cell = [&]() -> uint32_t {
         int x = 0;
         if (nfree > 0) {
+            if (RULES == MSNAKE_RULES_ADVERSARIAL) ensure_draws(1);  // its respawn count is not known up front
             const uint32_t k = randint((uint32_t)nfree);
             const int L = __builtin_ffsll((long long)ballot(freescan > k)) - 1;  // chunk holding the k-th free cell
             const uint64_t m = ((uint64_t)rdlane((uint32_t)(freemask >> 32), L) << 32) | rdlane((uint32_t)freemask, L);
@@ -334,6 +339,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             HV_SET(HDR_CTR_LO, nlo);
             if (nlo < ctr_lo) { HV_SET(HDR_CTR_HI, ctr_hi + 1); draws_valid = false; }
         } else {
+            ensure_draws(2u * NS + (uint32_t)nf);  // <= 40
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const uint32_t c0 = randint((uint32_t)dim), c1 = randint((uint32_t)dim);
@@ -382,17 +388,19 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // wave, a whole number of 1 KiB wave-instructions so that no lane needs a predicate.
     // (Storing the background to HBM right here, ahead of the logic, was measured and is SLOWER:
     //  the 16 MB of early stores clog each CU's memory pipe in front of every later access.)
+    // It goes memory -> LDS directly (global_load_lds_dwordx4: lane l's 16 bytes land at
+    // M0 base + 16*l), so the copy holds no data VGPRs and needs no ds_write.
     if (obs_t) {
         const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl) + lane;
-        uint4* dst = reinterpret_cast<uint4*>(img) + lane;
-        int k = 0;
         const int nk = img_bytes >> 10;
-        for (; k + 4 <= nk; k += 4) {
-            const uint4 t0 = tsrc[(k + 0) * 64], t1 = tsrc[(k + 1) * 64], t2 = tsrc[(k + 2) * 64], t3 = tsrc[(k + 3) * 64];
-            dst[(k + 0) * 64] = t0; dst[(k + 1) * 64] = t1; dst[(k + 2) * 64] = t2; dst[(k + 3) * 64] = t3;
-        }
-        for (; k < nk; ++k) dst[k * 64] = tsrc[k * 64];
+        for (int k = 0; k < nk; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tsrc + k * 64),
+                                             (__attribute__((address_space(3))) void*)(img + k * 1024), 16, 0, 0);
     }
+    // every load issued so far (state, actions, background) has landed past this point: the env
+    // logic needs the state right away, and the painters must find the background in LDS.  No
+    // store of this step has been issued yet, so this waits for loads only.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (STEPS) {
         float reward = 0.0f;
@@ -446,6 +454,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 if (m == 0) continue;
                 bf_pop = (v_moves && v_len >= v_grow + 2 * __builtin_popcount(v_em)) ? 1u : 0u;  // lanes <= s are final
                 bf_moved = (uint32_t)mvmask & ((2u << s) - 1u);
+                ensure_draws((uint32_t)__builtin_popcount(m));
                 build_free();
                 while (m) {
                     const int f = __builtin_ffs((int)m) - 1;
@@ -558,6 +567,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     }
                     HV_SET(HDR_SPARE, (uint32_t)spare);
                 } else {
+                    ensure_draws((uint32_t)neat);
                     build_free();
                     uint64_t m = em;
                     while (m) {
