@@ -88,10 +88,12 @@ __device__ __forceinline__ uint32_t philox_draws(uint32_t base_lo, uint32_t base
     uint32_t c0 = (d_lo >> 2) | (d_hi << 30), c1 = d_hi >> 2, c2 = g_lo, c3 = g_hi;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        const uint32_t n0 = __umulhi(0xCD9E8D57u, c2) ^ c1 ^ k0;
-        c1 = 0xCD9E8D57u * c2;
-        const uint32_t n2 = __umulhi(0xD2511F53u, c0) ^ c3 ^ k1;
-        c3 = 0xD2511F53u * c0;
+        // full 64-bit products: one v_mad_u64_u32 each instead of a v_mul_hi + v_mul_lo pair
+        const uint64_t p0 = (uint64_t)0xCD9E8D57u * c2, p1 = (uint64_t)0xD2511F53u * c0;
+        const uint32_t n0 = (uint32_t)(p0 >> 32) ^ c1 ^ k0;
+        c1 = (uint32_t)p0;
+        const uint32_t n2 = (uint32_t)(p1 >> 32) ^ c3 ^ k1;
+        c3 = (uint32_t)p1;
         c0 = n0; c2 = n2;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
