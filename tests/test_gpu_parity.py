@@ -446,6 +446,14 @@ def test_unusual_grid_sizes(dim, ns, nf, rules):
     _run_vs_oracle(n, dim, ns, nf, rules, 60, seed=31, greedy=0.5)
 
 
+@pytest.mark.parametrize("dim,ns", [(3, 2), (3, 3), (4, 3), (5, 2), (6, 3)])
+def test_small_boards_stress_respawn_ordering(dim, ns):
+    """Tiny boards: eaten fruits respawn next to (or under the next head of) the other snakes all the
+    time, so the order "snake s moves, its fruits respawn, snake s+1 moves" ([S]:119-141) decides the
+    outcome in a large share of the steps; several snakes eat in one step; boards fill up."""
+    assert _run_vs_oracle(4096, dim, ns, ns, "snake_env", 150, seed=41 + dim, greedy=0.3) > 1000
+
+
 def test_step_is_hip_graph_capturable():
     """msnake_step does no allocation, copy or synchronisation, so a caller can capture it (with
     its policy) into a HIP graph; replays must equal direct launches."""
