@@ -49,8 +49,11 @@ class CnnPolicy(nn.Module):
     # trunk runs on plain NCHW batch chunks.
     CONV_CHUNK = 1024
 
-    def __init__(self, ob_shape, n_actions=5, atari_size=None):
+    def __init__(self, ob_shape, n_actions=5, atari_size=None, amp_dtype=None):
         super().__init__()
+        # opt-in mixed precision (torch.bfloat16): the trunk runs under autocast on MFMA, parameters,
+        # heads' outputs, loss and optimizer stay fp32.  The reference trains in fp32, so None is the default.
+        self.amp_dtype = amp_dtype
         h, w, c = ob_shape
         atari_size = (h == 84) if atari_size is None else atari_size
         g = float(np.sqrt(2))
@@ -70,11 +73,13 @@ class CnnPolicy(nn.Module):
     def forward(self, ob_u8):
         """ob_u8: uint8 [B, H, W, 3] (NHWC like the env emits) -> logits [B, A], value [B]."""
         feats = []
-        for i in range(0, ob_u8.shape[0], self.CONV_CHUNK):
-            x = ob_u8[i:i + self.CONV_CHUNK].permute(0, 3, 1, 2).contiguous().float() / 255.0  # plain NCHW
-            feats.append(self.convs(x).flatten(1))
-        x = F.relu(self.fc1(torch.cat(feats) if len(feats) > 1 else feats[0]))
-        return self.pi(x), self.v(x)[:, 0]
+        with torch.autocast(ob_u8.device.type, dtype=self.amp_dtype or torch.bfloat16, enabled=self.amp_dtype is not None):
+            for i in range(0, ob_u8.shape[0], self.CONV_CHUNK):
+                x = ob_u8[i:i + self.CONV_CHUNK].permute(0, 3, 1, 2).contiguous().float() / 255.0  # plain NCHW
+                feats.append(self.convs(x).flatten(1))
+            x = F.relu(self.fc1(torch.cat(feats) if len(feats) > 1 else feats[0]))
+            logits, v = self.pi(x), self.v(x)[:, 0]
+        return logits.float(), v.float()
 
     @torch.no_grad()
     def step(self, ob_u8):
@@ -250,14 +255,14 @@ class Runner:
 def learn(env, nsteps=64, total_timesteps=int(1e6), ent_coef=0.01, lr=lambda f: f * 2.5e-4, vf_coef=0.5,
           max_grad_norm=0.5, gamma=0.99, lam=0.95, log_interval=1, nminibatches=8, noptepochs=4,
           cliprange=lambda f: f * 0.1, opponent_save_interval=50, max_saved_opponents=1000, csv_path=None,
-          monitor_path=None, seed=0, log_fn=print):
+          monitor_path=None, seed=0, log_fn=print, amp_dtype=None):
     """ppo_multi_agent.py:231-404 (hyper-parameters of test/ppo1_single_test.py:42-47 as defaults)."""
     torch.manual_seed(seed); random.seed(seed)
     dev = env.device
     n_snakes = env.n_snakes
     H, W, _ = env.obs_shape
-    model = CnnPolicy((H, W, 3)).to(dev)
-    opponents = [CnnPolicy((H, W, 3)).to(dev) for _ in range(n_snakes - 1)]
+    model = CnnPolicy((H, W, 3), amp_dtype=amp_dtype).to(dev)
+    opponents = [CnnPolicy((H, W, 3), amp_dtype=amp_dtype).to(dev) for _ in range(n_snakes - 1)]
     pools = [OpponentPool(max_saved_opponents) for _ in opponents]
     for pool in pools:
         pool.save(model)

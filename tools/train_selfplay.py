@@ -18,16 +18,18 @@ def main():
     ap.add_argument("--nsteps", type=int, default=64)
     ap.add_argument("--timesteps", type=int, default=int(2e6))
     ap.add_argument("--scale", type=int, default=1, help="4 = 84x84 frames (nature_cnn) at dim 19")
+    ap.add_argument("--bf16", action="store_true", help="policy trunk under bf16 autocast (reference: fp32)")
     ap.add_argument("--csv", default=None)
     ap.add_argument("--monitor", default=None)
     args = ap.parse_args()
+    import torch
     import msnake
     from msnake import selfplay
 
     env = msnake.MultiSnakeVecEnv(args.envs, dim=args.dim, n_snakes=args.snakes, rules=args.rules, seed=0,
                                   obs_scale=args.scale)
     selfplay.learn(env, nsteps=args.nsteps, total_timesteps=args.timesteps, csv_path=args.csv,
-                   monitor_path=args.monitor)
+                   monitor_path=args.monitor, amp_dtype=torch.bfloat16 if args.bf16 else None)
     print(env.stats())
     env.close()
 
