@@ -45,6 +45,11 @@ def load():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C <pkg>/csrc). "
             "There is no CPU fallback.")
+    # torch first: its wheel bundles a HIP runtime with the SONAME libmsnake.so links against
+    # (libamdhip64.so.7), and the device pointers / streams handed to the library come from it.
+    # Loading libmsnake.so before torch would pull /opt/rocm's copy in as a SECOND runtime in the
+    # process, and that one finds no device (msnake_create -> MSNAKE_E_NOGPU).
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, u8p = ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p
     L.msnake_abi_version.restype = ctypes.c_int

@@ -115,3 +115,20 @@ def test_shard_range_partitions_exactly():
             assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
     with pytest.raises(ValueError):
         msnake.shard_range(8, 2, 2)
+
+
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """build() loads libmsnake.so before smoke() imports torch: the library must still bind to the
+    HIP runtime torch brings (same SONAME), not pull /opt/rocm's copy in as a second runtime -- with
+    two runtimes in one process the second one finds no device (seen on the GPU box)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import msnake; msnake._capi.load()\n"
+            "import torch\n"
+            "paths = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}\n"
+            "print(len(paths), sorted(paths))\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == "1", out.stdout
