@@ -135,7 +135,16 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = (int)uni(threadIdx.x >> 6);
-    const int e = (int)(blockIdx.x * (blockDim.x >> 6)) + wave;
+    // XCD-aware env mapping: consecutive workgroup ids go round-robin to the 8 XCDs, so within
+    // every aligned group of 64 workgroups XCD x takes 8 CONSECUTIVE env blocks (bits 0-2 and 3-5 of
+    // the id swapped).  Each XCD's L2 then writes 32-env runs of the observation tensor (127 KB
+    // contiguous) instead of 4-env pieces whose edge cache lines it shares with two other XCDs.
+    // An incomplete last group keeps the identity mapping.  (Measured: 0.4 % less WRITE_SIZE, launch
+    // time unchanged -- the envs share nothing else across workgroups.)
+    const uint32_t epb = blockDim.x >> 6;
+    uint32_t b = blockIdx.x;
+    if ((b | 63u) * epb < (uint32_t)nenv) b = (b & ~63u) | ((b & 7u) << 3) | ((b >> 3) & 7u);
+    const int e = (int)(b * epb) + wave;
     if (e >= nenv) return;
 
     // pk0 = dim | n_fruits<<6 | action_stride<<12 | auto_reset<<15 | max_steps<<16 ; pk1 = S | cap<<16
