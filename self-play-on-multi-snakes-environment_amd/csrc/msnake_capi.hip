@@ -194,6 +194,19 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
         const int v = atoi(epb);
         if (v >= 1 && v <= h->epb) h->epb = v;
     }
+    // obs_store_policy: should the observation stores carry the nt (streaming) hint?  Measured on
+    // MI355X with the native 16-byte-per-lane copy-out (tools/kbench.py, MSNAKE_NT=0/1), per launch:
+    //   <= 32 MiB of observations (<= 8 192 envs at 19x19x3; fits the 8 L2s): 2-3 % faster with nt
+    //      (nothing is left to write back when the kernel ends);
+    //   64-130 MiB (fits the 256 MB Infinity Cache): 0-4 % slower (a re-used buffer no longer hits);
+    //   >= 260 MiB: 33-42 % faster (388 -> 243 us at 262 144 envs: plain stores thrash the cache).
+    // The fused x4 / x7 copy-out stores dwords (256 B per wave instruction) and is 2.5x SLOWER with
+    // nt, so it never streams; neither does the persistent tape kernel (187 -> 208 us).
+    {
+        const double obs_mib = (double)p.nenv * p.S * p.obs_scale * p.obs_scale / (1024.0 * 1024.0);
+        p.rest.stream_obs = (p.obs_scale == 1 && (obs_mib <= 32.0 || obs_mib >= 192.0)) ? 1u : 0u;
+    }
+    if (const char* nt = getenv("MSNAKE_NT")) p.rest.stream_obs = atoi(nt) ? 1u : 0u;  // experiment knob
     if (const char* dbg = getenv("MSNAKE_DBG_STAGE")) p.rest.dbg_stage = (uint32_t)atoi(dbg);
     if (const char* dbg = getenv("MSNAKE_DBG_BUF")) p.rest.dbg_buf = reinterpret_cast<unsigned long long*>(strtoull(dbg, nullptr, 0));
     h->magic = kMagic;

@@ -51,6 +51,7 @@ struct StepRest {
     int32_t n_steps;             // MODE 3 (msnake_rollout_tape): steps per launch
     uint64_t obs_step_stride;    // MODE 3: bytes between consecutive steps' observations (0 = overwrite)
     uint64_t scalar_step_stride; // MODE 3: elements between consecutive steps' rew/done/info
+    uint32_t stream_obs;         // observation stores carry the nt (streaming) hint
 };
 
 struct StepParams {

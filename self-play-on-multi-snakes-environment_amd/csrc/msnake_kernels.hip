@@ -116,6 +116,8 @@ __device__ __forceinline__ bool in_grid(uint32_t cell, int dim) {
 #define HV_SET(idx, val) hv = (lane == (idx)) ? (uint32_t)(val) : hv
 
 typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
 
 // MODE 0: step, 1: reset every env (msnake_reset), 2: render only (msnake_render), 3: n_steps steps of
 //      an action tape in ONE launch with the env kept in registers (msnake_rollout_tape)
@@ -794,8 +796,13 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             //         S%16 bytes go singly.
             uint8_t* obs_env = obs_t + (size_t)e * S;
             const int nfull = S >> 4;
-            for (int k = lane; k < nfull; k += 64)
-                *reinterpret_cast<uint4_unaligned*>(obs_env + 16 * k) = reinterpret_cast<const uint4*>(img)[k];
+            if (MODE != 3 && p.stream_obs) {  // streaming (nt) stores, see msnake_capi.hip: obs_store_policy
+                for (int k = lane; k < nfull; k += 64)
+                    __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(img)[k], reinterpret_cast<u32x4_unaligned*>(obs_env + 16 * k));
+            } else {
+                for (int k = lane; k < nfull; k += 64)
+                    *reinterpret_cast<uint4_unaligned*>(obs_env + 16 * k) = reinterpret_cast<const uint4*>(img)[k];
+            }
             const int tail = (nfull << 4) + lane;
             if (tail < S) obs_env[tail] = img[tail];
         } else {
@@ -806,12 +813,21 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             uint32_t* out = reinterpret_cast<uint32_t*>(obs_t + (size_t)e * S * (K * K));
             const uint32_t* src = reinterpret_cast<const uint32_t*>(img);
             const int rowdw = (W * K * C) >> 2;
-            for (int r = 0; r < W; ++r)
-                for (int q = lane; q < rowdw; q += 64) {
-                    const uint32_t v = src[r * rowdw + q];
+            if (MODE != 3 && p.stream_obs) {
+                for (int r = 0; r < W; ++r)
+                    for (int q = lane; q < rowdw; q += 64) {
+                        const uint32_t v = src[r * rowdw + q];
 #pragma unroll
-                    for (int rr = 0; rr < K; ++rr) out[(size_t)(r * K + rr) * rowdw + q] = v;
-                }
+                        for (int rr = 0; rr < K; ++rr) __builtin_nontemporal_store(v, &out[(size_t)(r * K + rr) * rowdw + q]);
+                    }
+            } else {
+                for (int r = 0; r < W; ++r)
+                    for (int q = lane; q < rowdw; q += 64) {
+                        const uint32_t v = src[r * rowdw + q];
+#pragma unroll
+                        for (int rr = 0; rr < K; ++rr) out[(size_t)(r * K + rr) * rowdw + q] = v;
+                    }
+            }
         }
     }
     STAMP(6);
