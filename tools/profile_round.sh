@@ -11,6 +11,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 ARGS="--steps 1024 --warmup 64 --no-cpu-baseline --no-rollout"
+# the same command without the profiler, on the same box: rocprofv3 serialises the dispatches and
+# lengthens both the kernels and the gaps between them, and boxes differ by a few per cent
+python3 $R/bench.py $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err || echo "plain bench failed"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py $ARGS > $OUT/kt.log 2>&1 || echo "kernel-trace pass failed"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1 || echo "FETCH_SIZE pass failed"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS > $OUT/pmc_write.log 2>&1 || echo "WRITE_SIZE pass failed"
