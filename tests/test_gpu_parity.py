@@ -120,6 +120,12 @@ def test_config3_4096_envs_19x19_3snakes():
     assert _run_vs_oracle(4096, 19, 3, 3, "snake_env", 200, seed=0) > 1000
 
 
+def test_config3_with_plain_observation_stores(monkeypatch):
+    """4 096 envs stream their observation stores by default; batches of 64-130 MiB use plain ones."""
+    monkeypatch.setenv("MSNAKE_NT", "0")
+    assert _run_vs_oracle(4096, 19, 3, 3, "snake_env", 60, seed=5) > 300
+
+
 def test_config5_shape_19x19_2snakes_long_lived():
     _run_vs_oracle(2048, 19, 2, 2, "snake_env", 300, seed=4, greedy=0.7)
 
@@ -136,12 +142,16 @@ def test_new_world_4096_envs():
     _run_vs_oracle(256, 10, 4, 4, "new_world", 100, seed=3)
 
 
+@pytest.mark.parametrize("stores", ["plain", "streaming"])
 @pytest.mark.parametrize("num_envs", [1, 2, 5, 17, 63, 130])
-def test_ragged_batch_sizes_and_unaligned_images(num_envs):
+def test_ragged_batch_sizes_and_unaligned_images(num_envs, stores, monkeypatch):
     """3969-byte images are not 16-byte multiples: every misalignment 0..15 of the per-env image
-    and the byte-store edges are exercised; guard bytes around the tensor must stay untouched."""
+    and the byte-store edges are exercised; guard bytes around the tensor must stay untouched.
+    Both copy-out variants (plain and nt/streaming stores; the library picks one by batch size,
+    MSNAKE_NT forces it at create time) must produce the same bytes."""
     import torch
     from oracle.snake_oracle import Oracle
+    monkeypatch.setenv("MSNAKE_NT", "1" if stores == "streaming" else "0")
     env = _mk(num_envs=num_envs, dim=19, n_snakes=3, rules="snake_env", seed=9)
     ora = Oracle(num_envs, dim=19, n_snakes=3, rules="snake_env", seed=9)
     H, W, C = env.obs_shape
