@@ -7,9 +7,9 @@
 
 #include "../../include/msnake.h"
 
-// One wavefront per env; up to 4 envs (256 threads) per workgroup, no workgroup barrier anywhere.
-#define MSNAKE_BLOCK_THREADS 256
-#define MSNAKE_MAX_ENVS_PER_BLOCK 4
+// One wavefront per env; up to 8 envs (512 threads) per workgroup, no workgroup barrier anywhere.
+#define MSNAKE_BLOCK_THREADS 512
+#define MSNAKE_MAX_ENVS_PER_BLOCK 8
 
 // Per-env record in HBM: 64 dwords = 256 B, loaded/stored by ONE coalesced wave instruction
 // (lane l <-> word l), plus 128 B per snake with its first 64 body cells in logical order.  Both

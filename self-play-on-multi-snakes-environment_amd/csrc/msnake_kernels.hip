@@ -1,7 +1,7 @@
 // msnake_kernels.hip -- the batched multi-snake environment step for gfx950 (MI355X, CDNA4).
 //
-// One 64-lane wavefront owns one environment for the whole step; a 256-thread workgroup carries
-// four independent envs and never executes a workgroup barrier.  Design points:
+// One 64-lane wavefront owns one environment for the whole step; a 512- or 256-thread workgroup carries
+// eight or four independent envs and never executes a workgroup barrier.  Design points:
 //   * ONE memory round trip before the wave can decide: the 256-byte env record (lane l <-> word
 //     l), the first 64 body cells of every snake (lane l <-> piece l) and the actions are all at
 //     addresses that depend only on the env index, so they are issued together at kernel entry.
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     const int wave = (int)uni(threadIdx.x >> 6);
     // XCD-aware env mapping: consecutive workgroup ids go round-robin to the 8 XCDs, so within
     // every aligned group of 64 workgroups XCD x takes 8 CONSECUTIVE env blocks (bits 0-2 and 3-5 of
-    // the id swapped).  Each XCD's L2 then writes 32-env runs of the observation tensor (127 KB
-    // contiguous) instead of 4-env pieces whose edge cache lines it shares with two other XCDs.
+    // the id swapped).  Each XCD's L2 then writes runs of 8 workgroups' envs of the observation tensor
+    // (127-254 KB contiguous) instead of single-workgroup pieces whose edge cache lines it shares with two other XCDs.
     // An incomplete last group keeps the identity mapping.  (Measured: 0.4 % less WRITE_SIZE, launch
     // time unchanged -- the envs share nothing else across workgroups.)
     const uint32_t epb = blockDim.x >> 6;
