@@ -32,6 +32,13 @@
 #define HDR_ACC_RETURN 26    // int32, rewards are integral
 #define HDR_ACC_ERRORS 27
 #define HDR_FRUIT0 32    // word 32+f: fruit f's cell (snake_env / new_world keep fruits inline)
+// snake_env / adversarial (at most 3 inline fruits): the free tail of the record carries the next
+// Philox draws, so the waves that respawn a fruit or reset -- the last ones to finish in a launch --
+// rarely have to evaluate Philox themselves.  It rides along with the record: no extra traffic.
+#define HDR_PC_VALID 35  // 1: words 37..63 hold the u32 of draws [PC_BASE, PC_BASE + 27)
+#define HDR_PC_BASE 36   // low 32 bits of the first cached draw's index
+#define HDR_PC_FIRST 37
+#define HDR_PC_N 27
 
 #define MSNAKE_NO_CELL 0xFFFFu  // never equals a real cell (rows/cols <= 63)
 

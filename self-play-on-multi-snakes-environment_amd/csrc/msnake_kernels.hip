@@ -203,8 +203,11 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 
     // ---- RNG: randint(n) = (u32 * n) >> 32 on draw number ctr (kept in the record).  Slow paths
     //      only; `draws` caches the u32 of draws [draw_base, draw_base + 64) --------------------
-    uint32_t draws = 0, draw_base = 0;
-    bool draws_valid = false;
+    //      `draws_n` of them are valid: 64 after a Philox evaluation, 27 when they were taken from
+    //      the record's cache words (HDR_PC_*), 0 = none.
+    constexpr bool PCACHE = RULES != MSNAKE_RULES_NEW_WORLD;  // new_world's fruits may fill the record
+    uint32_t draws = 0, draw_base = 0, draws_n = 0;
+    bool refilled = false;
     auto refill_draws = [&](uint32_t ctr_lo, uint32_t ctr_hi) {
         const uint64_t gid = p.env_id_base + (uint64_t)e;
         uint32_t k0 = p.seed_lo, k1 = p.seed_hi;
@@ -212,20 +215,34 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         // where it would pin 20 SGPRs for every wave
         asm volatile("" : "+s"(k0), "+s"(k1));
         draws = philox_draws(ctr_lo, ctr_hi, lane, (uint32_t)gid, (uint32_t)(gid >> 32), k0, k1);
-        draw_base = ctr_lo; draws_valid = true;
+        draw_base = ctr_lo; draws_n = 64; refilled = true;
     };
     // the next `need` (<= 64) draws are cached afterwards.  Callers run this BEFORE they build
     // their wide temporaries (free-cell masks), so Philox does not set the kernel's VGPR peak.
     auto ensure_draws = [&](uint32_t need) {
         const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
-        if (!draws_valid || ctr_lo - draw_base > 64u - need) refill_draws(ctr_lo, ctr_hi);
+        if (need <= draws_n && ctr_lo - draw_base <= draws_n - need) return;
+        if (PCACHE && !refilled && need <= HDR_PC_N && rdlane(hv, HDR_PC_VALID) == 1u) {
+            const uint32_t pb = rdlane(hv, HDR_PC_BASE);
+            if (ctr_lo - pb <= HDR_PC_N - need) {
+                draws = (uint32_t)__shfl((int)hv, lane + HDR_PC_FIRST);  // lane l <- record word 37 + l
+                draw_base = pb; draws_n = HDR_PC_N;
+                return;
+            }
+        }
+        refill_draws(ctr_lo, ctr_hi);
+    };
+    auto ctr_wrapped = [&](uint32_t ctr_hi) {  // once per 2^32 draws: drop both caches
+        HV_SET(HDR_CTR_HI, ctr_hi + 1);
+        draws_n = 0;
+        if (PCACHE) HV_SET(HDR_PC_VALID, 0u);
     };
     auto randint = [&](uint32_t n) -> uint32_t {  // ensure_draws() has covered this draw
         const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
         const uint32_t u = rdlane(draws, (int)((ctr_lo - draw_base) & 63u));
         const uint32_t nlo = ctr_lo + 1;
         HV_SET(HDR_CTR_LO, nlo);
-        if (nlo == 0) { HV_SET(HDR_CTR_HI, ctr_hi + 1); draws_valid = false; }
+        if (nlo == 0) ctr_wrapped(ctr_hi);
         return (uint32_t)(((uint64_t)u * n) >> 32);
     };
 
@@ -328,9 +345,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         if (RULES != MSNAKE_RULES_NEW_WORLD) {
             // [S]:223-225 draws snake s's cell then fruit s's cell, each (randint(dim), randint(dim)):
             // 4*NS consecutive draws.  All of them at once: lane l takes draw ctr + l.
+            ensure_draws(4u * NS);
             const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
-            uint32_t idx0 = ctr_lo - draw_base;
-            if (!draws_valid || idx0 + 4u * NS > 64u) { refill_draws(ctr_lo, ctr_hi); idx0 = 0; }
+            const uint32_t idx0 = ctr_lo - draw_base;
             const uint32_t u = (uint32_t)__shfl((int)draws, (int)idx0 + lane);
             const uint32_t v = (uint32_t)(((uint64_t)u * (uint32_t)dim) >> 32) + 1u;  // padded coordinate
             const uint32_t cellv = (v << 8) | row_shl<1>(0u, v);                     // even lanes: (c0+1, c1+1)
@@ -350,7 +367,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             }
             const uint32_t nlo = ctr_lo + 4u * NS;
             HV_SET(HDR_CTR_LO, nlo);
-            if (nlo < ctr_lo) { HV_SET(HDR_CTR_HI, ctr_hi + 1); draws_valid = false; }
+            if (nlo < ctr_lo) ctr_wrapped(ctr_hi);
         } else {
             ensure_draws(2u * NS + (uint32_t)nf);  // <= 40
 #pragma unroll
@@ -835,6 +852,19 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 
     // ---- 5. state write-back (once per launch) ---------------------------
     if (MODE != 2) {
+        if (PCACHE && refilled) {
+            // Philox ran in this launch: its unused draws go into the record for the launches to come
+            const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO);
+            const uint32_t off = ctr_lo - draw_base;
+            if (draws_n == 64 && off + HDR_PC_N <= 64u) {
+                const uint32_t sh = (uint32_t)__shfl((int)draws, lane - HDR_PC_FIRST + (int)off);
+                hv = lane >= HDR_PC_FIRST ? sh : hv;
+                HV_SET(HDR_PC_BASE, ctr_lo);
+                HV_SET(HDR_PC_VALID, 1u);
+            } else {
+                HV_SET(HDR_PC_VALID, 0u);
+            }
+        }
         hdr_g[lane] = hv;
 #pragma unroll
         for (int s = 0; s < NS; ++s) body0_g[s * 64 + lane] = (uint16_t)cr[s];

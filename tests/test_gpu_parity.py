@@ -464,6 +464,36 @@ def test_small_boards_stress_respawn_ordering(dim, ns):
     assert _run_vs_oracle(4096, dim, ns, ns, "snake_env", 150, seed=41 + dim, greedy=0.3) > 1000
 
 
+@pytest.mark.parametrize("rules", ["snake_env", "adversarial", "new_world"])
+def test_draw_counter_crosses_32_bits(rules):
+    """The Philox draw counter is 64 bit; env e starts 3*e draws below 2**32, so the in-register
+    draw cache, the draws parked in the record between launches and the counter's carry all cross
+    the boundary at different phases (resets take 12 draws at once, respawns one)."""
+    from oracle.snake_oracle import Oracle
+    n, dim, ns = 96, 6, 3
+    nf = 3 if rules != "new_world" else 4
+    env = _mk(num_envs=n, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=21)
+    ora = Oracle(n, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=21)
+    env.reset(); ora.reset()
+    for e in range(n):
+        st = ora.get_state(e)
+        st["ctr"] = (1 << 32) - (3 * e if rules != "new_world" else e % 10)  # new_world draws rarely
+        _set_state(env, e, st); ora.set_state(e, st)
+    rs = np.random.default_rng(5)
+    for t in range(120):
+        act = rs.integers(0, 5, (n, ns)).astype(np.int32)
+        obs, rew, done, infos = env.step(act)
+        o_obs, o_rew, o_done, o_ns, o_er, o_el = ora.step(act)
+        assert np.array_equal(obs, o_obs) and np.array_equal(rew, o_rew) and np.array_equal(done, o_done.astype(bool)), t
+    crossed = 0
+    for e in range(n):
+        got, want = _state(env, e), ora.get_state(e)
+        assert got == want, e
+        crossed += got["ctr"] >= (1 << 32)
+    assert crossed > n // 4
+    env.close()
+
+
 def test_step_is_hip_graph_capturable():
     """msnake_step does no allocation, copy or synchronisation, so a caller can capture it (with
     its policy) into a HIP graph; replays must equal direct launches."""
