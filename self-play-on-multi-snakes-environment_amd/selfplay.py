@@ -21,6 +21,7 @@ n pipes and NumPy, and sleeps 0.1 s per rollout step, ppo_multi_agent.py:175).
 Parity with the reference here is statistical (learning curves), not bit-exact.
 """
 import json
+import os
 import random
 import time
 from collections import deque
@@ -186,6 +187,94 @@ class CSVLogger:
         self.file.close()
 
 
+class JSONLogger:
+    """baselines.logger.JSONOutputFormat (logger.py:86-99): one JSON object per writekvs, per line."""
+
+    def __init__(self, filename):
+        self.file = open(filename, "wt")
+
+    def writekvs(self, kvs):
+        self.file.write(json.dumps({k: (float(v) if hasattr(v, "dtype") else v) for k, v in kvs.items()}) + "\n")
+        self.file.flush()
+
+    def close(self):
+        self.file.close()
+
+
+def _crc32c_table():
+    t = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+        t.append(c)
+    return t
+
+
+_CRC32C = _crc32c_table()
+
+
+def crc32c(data):
+    c = 0xFFFFFFFF
+    for b in data:
+        c = _CRC32C[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def _masked_crc(data):
+    c = crc32c(data)
+    return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def _varint(n):
+    out = bytearray()
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        out.append(b | (0x80 if n else 0))
+        if not n:
+            return bytes(out)
+
+
+class TensorBoardLogger:
+    """baselines.logger.TensorBoardOutputFormat (logger.py:136-170) without TensorFlow: an
+    `events.out.tfevents.*` file of TFRecord-framed Event protos (wall_time, step, one
+    Summary.Value{tag, simple_value} per key), step counting from 1 like the reference.  The few
+    proto fields involved are encoded by hand; records carry the masked CRC32C TensorBoard checks."""
+
+    def __init__(self, directory):
+        import socket
+        import struct
+        self._struct = struct
+        os.makedirs(directory, exist_ok=True)
+        self.path = os.path.join(directory, "events.out.tfevents.%d.%s" % (int(time.time()), socket.gethostname()))
+        self.file = open(self.path, "wb")
+        self.step = 1
+        ver = b"brain.Event:2"
+        self._record(b"\x09" + struct.pack("<d", time.time()) + b"\x1a" + _varint(len(ver)) + ver)
+
+    def _record(self, data):
+        st = self._struct
+        head = st.pack("<Q", len(data))
+        self.file.write(head + st.pack("<I", _masked_crc(head)) + data + st.pack("<I", _masked_crc(data)))
+        self.file.flush()
+
+    def writekvs(self, kvs):
+        st = self._struct
+        summary = b""
+        for k, v in kvs.items():
+            tag = str(k).encode()
+            value = b"\x0a" + _varint(len(tag)) + tag + b"\x15" + st.pack("<f", float(v))
+            summary += b"\x0a" + _varint(len(value)) + value
+        event = (b"\x09" + st.pack("<d", time.time()) + b"\x10" + _varint(self.step) +
+                 b"\x2a" + _varint(len(summary)) + summary)
+        self._record(event)
+        self.step += 1
+
+    def close(self):
+        self.file.close()
+
+
 class MonitorCSV:
     """baselines.bench.Monitor's file: '#{"t_start":..,"env_id":..}' then r,l,t rows."""
 
@@ -255,7 +344,7 @@ class Runner:
 def learn(env, nsteps=64, total_timesteps=int(1e6), ent_coef=0.01, lr=lambda f: f * 2.5e-4, vf_coef=0.5,
           max_grad_norm=0.5, gamma=0.99, lam=0.95, log_interval=1, nminibatches=8, noptepochs=4,
           cliprange=lambda f: f * 0.1, opponent_save_interval=50, max_saved_opponents=1000, csv_path=None,
-          monitor_path=None, seed=0, log_fn=print, amp_dtype=None):
+          monitor_path=None, seed=0, log_fn=print, amp_dtype=None, json_path=None, tb_dir=None):
     """ppo_multi_agent.py:231-404 (hyper-parameters of test/ppo1_single_test.py:42-47 as defaults)."""
     torch.manual_seed(seed); random.seed(seed)
     dev = env.device
@@ -273,7 +362,11 @@ def learn(env, nsteps=64, total_timesteps=int(1e6), ent_coef=0.01, lr=lambda f: 
     assert nbatch % nminibatches == 0
     nupdates = max(1, total_timesteps // nbatch)
     epinfobuf = deque(maxlen=100)
-    csv = CSVLogger(csv_path) if csv_path else None
+    sinks = [CSVLogger(csv_path)] if csv_path else []  # the reference's LOG_FORMAT sinks (logger.py:172-186)
+    if json_path:
+        sinks.append(JSONLogger(json_path))
+    if tb_dir:
+        sinks.append(TensorBoardLogger(tb_dir))
     mon = MonitorCSV(monitor_path, "msnake") if monitor_path else None
     history, tfirst = [], time.time()
     for update in range(1, nupdates + 1):
@@ -319,12 +412,12 @@ def learn(env, nsteps=64, total_timesteps=int(1e6), ent_coef=0.01, lr=lambda f: 
                 kvs["num_opponents"] = pools[0].num
             kvs.update(dict(zip(("policy_loss", "value_loss", "policy_entropy", "approxkl", "clipfrac"), lossvals)))
             history.append(kvs)
-            if csv:
-                csv.writekvs(kvs)
+            for sink in sinks:
+                sink.writekvs(kvs)
             if log_fn:
                 log_fn(" ".join(f"{k}={v:.4g}" if isinstance(v, float) else f"{k}={v}" for k, v in kvs.items()))
-    if csv:
-        csv.close()
+    for sink in sinks:
+        sink.close()
     if mon:
         mon.close()
     return model, history

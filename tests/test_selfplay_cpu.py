@@ -88,3 +88,66 @@ def test_csv_logger_is_readable_like_the_reference_plots(tmp_path):
     mon.close()
     lines = open(tmp_path / "m.monitor.csv").read().splitlines()
     assert lines[0].startswith('#{"t_start"') and lines[1] == "r,l,t" and lines[2] == "3.0,21,1.5"
+
+
+def test_json_and_tensorboard_sinks_round_trip(tmp_path):
+    """logger.py:86-99 JSON lines and logger.py:136-170 TensorBoard events (written without TensorFlow):
+    CRC32C known answers, TFRecord framing with masked CRCs, Event/Summary fields decoded back."""
+    import json
+    import struct
+    from msnake import selfplay as sp
+    assert sp.crc32c(b"123456789") == 0xE3069283          # CRC-32C check value
+    assert sp.crc32c(b"\x00" * 32) == 0x8A9136AA           # RFC 3720 B.4
+    rows = [{"nupdates": 1, "fps": 1234, "eprewmean 100": -0.5, "policy_loss": 0.25},
+            {"nupdates": 2, "fps": 1300, "eprewmean 100": 0.125, "policy_loss": -0.75}]
+    js, tb = sp.JSONLogger(str(tmp_path / "progress.json")), sp.TensorBoardLogger(str(tmp_path / "tb"))
+    for r in rows:
+        js.writekvs(r); tb.writekvs(r)
+    js.close(); tb.close()
+    assert [json.loads(l) for l in open(tmp_path / "progress.json")] == rows
+
+    def varint(b, i):
+        v = s = 0
+        while True:
+            v |= (b[i] & 0x7F) << s
+            s += 7
+            i += 1
+            if not b[i - 1] & 0x80:
+                return v, i
+
+    def fields(b):
+        i, out = 0, []
+        while i < len(b):
+            key, i = varint(b, i)
+            f, wt = key >> 3, key & 7
+            if wt == 0:
+                v, i = varint(b, i)
+            elif wt == 1:
+                v, i = struct.unpack_from("<d", b, i)[0], i + 8
+            elif wt == 5:
+                v, i = struct.unpack_from("<f", b, i)[0], i + 4
+            else:
+                n, i = varint(b, i)
+                v, i = b[i:i + n], i + n
+            out.append((f, v))
+        return out
+
+    data = open(tb.path, "rb").read()
+    i, events = 0, []
+    while i < len(data):
+        (n,) = struct.unpack_from("<Q", data, i)
+        assert struct.unpack_from("<I", data, i + 8)[0] == sp._masked_crc(data[i:i + 8])
+        rec = data[i + 12:i + 12 + n]
+        assert struct.unpack_from("<I", data, i + 12 + n)[0] == sp._masked_crc(rec)
+        events.append(fields(rec))
+        i += 16 + n
+    assert len(events) == 3 and (3, b"brain.Event:2") in events[0]
+    for step, (ev, row) in enumerate(zip(events[1:], rows), 1):
+        ev = dict(ev)
+        assert ev[2] == step and ev[1] > 1e9
+        vals = {}
+        for f, v in fields(ev[5]):
+            assert f == 1
+            d = dict(fields(v))
+            vals[d[1].decode()] = d[2]
+        assert vals == {k: float(np.float32(v)) for k, v in row.items()}

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="policy trunk under bf16 autocast (reference: fp32)")
     ap.add_argument("--csv", default=None)
     ap.add_argument("--monitor", default=None)
+    ap.add_argument("--json", default=None, help="progress.json (baselines JSON log format)")
+    ap.add_argument("--tensorboard", default=None, help="directory for a TensorBoard events file")
     args = ap.parse_args()
     import torch
     import msnake
@@ -29,7 +31,7 @@ def main():
     env = msnake.MultiSnakeVecEnv(args.envs, dim=args.dim, n_snakes=args.snakes, rules=args.rules, seed=0,
                                   obs_scale=args.scale)
     selfplay.learn(env, nsteps=args.nsteps, total_timesteps=args.timesteps, csv_path=args.csv,
-                   monitor_path=args.monitor, amp_dtype=torch.bfloat16 if args.bf16 else None)
+                   monitor_path=args.monitor, json_path=args.json, tb_dir=args.tensorboard, amp_dtype=torch.bfloat16 if args.bf16 else None)
     print(env.stats())
     env.close()
 
