@@ -427,8 +427,12 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
         if (in_dead) flags |= 16u << s;
     }
     hdr[HDR_FLAGS] = flags;
+    // every other word stays 0: in particular HDR_PC_VALID, so draws parked in the record for the old
+    // counter value are dropped.  The env's logging totals are not part of the canonical state: keep them.
     DeviceGuard guard(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&hdr[HDR_ACC_EPISODES], p.hdr + (size_t)env * MSNAKE_HDR_WORDS + HDR_ACC_EPISODES,
+                      4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(p.hdr + (size_t)env * MSNAKE_HDR_WORDS, hdr, sizeof(hdr), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p.ring + (size_t)env * p.n_snakes * p.rest.cap, ring.data(), ring.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p.body0 + (size_t)env * p.n_snakes * 64, body0.data(), body0.size() * 2, hipMemcpyHostToDevice));

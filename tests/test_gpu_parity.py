@@ -494,6 +494,22 @@ def test_draw_counter_crosses_32_bits(rules):
     env.close()
 
 
+def test_set_state_keeps_the_logging_totals():
+    """Episode totals live in the env records; installing a canonical state (which does not carry
+    them) must not lose what msnake_get_stats will report."""
+    env = _mk(num_envs=32, dim=6, n_snakes=2, rules="snake_env", seed=3)
+    env.reset()
+    rs = np.random.default_rng(1)
+    for _ in range(60):
+        env.step(rs.integers(0, 5, (32, 2)).astype(np.int32))
+    before = env.stats()
+    assert before["episodes"] > 10
+    for e in range(32):
+        _set_state(env, e, _state(env, e))
+    assert env.stats() == before
+    env.close()
+
+
 def test_step_is_hip_graph_capturable():
     """msnake_step does no allocation, copy or synchronisation, so a caller can capture it (with
     its policy) into a HIP graph; replays must equal direct launches."""
