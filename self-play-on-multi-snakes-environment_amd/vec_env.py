@@ -98,6 +98,10 @@ class MultiSnakeVecEnv:
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError(f"device must be a cuda (HIP) device, got {self.device}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         rules_id = _capi.RULES[rules] if isinstance(rules, str) else int(rules)
         if n_fruits is None:
             n_fruits = n_snakes
@@ -138,8 +142,20 @@ class MultiSnakeVecEnv:
     def _stream(self):
         return ctypes.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _out(self, out):
+        """The kernel writes num_envs*H*W*C bytes through a raw pointer: a caller-supplied buffer must
+        be exactly that, on this device."""
+        if out is None:
+            return self._obs
+        torch = self._torch
+        want = (self.num_envs,) + self.obs_shape
+        if (not isinstance(out, torch.Tensor) or out.dtype != torch.uint8 or out.device != self.device or
+                tuple(out.shape) != want or not out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous uint8 tensor of shape {want} on {self.device}")
+        return out
+
     def reset_device(self, out=None):
-        obs = self._obs if out is None else out
+        obs = self._out(out)
         _capi.check(self._L.msnake_reset(self._h, obs.data_ptr(), self._stream()), "msnake_reset")
         return obs
 
@@ -148,18 +164,18 @@ class MultiSnakeVecEnv:
         (obs uint8[nenv,H,W,C], rew f32[nenv], done u8[nenv], info i32[nenv,4] = (ep_return bits,
         ep_len, num_snakes, done)); nothing is synchronised."""
         torch = self._torch
-        if actions.dtype != torch.int32 or not actions.is_cuda or not actions.is_contiguous():
+        if actions.dtype != torch.int32 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
         if actions.dim() != 2 or actions.shape[0] != self.num_envs or actions.shape[1] < self.n_snakes:
             raise ValueError(f"actions must be [{self.num_envs}, >={self.n_snakes}], got {tuple(actions.shape)}")
-        obs = self._obs if out is None else out
+        obs = self._out(out)
         _capi.check(self._L.msnake_step(self._h, actions.data_ptr(), int(actions.shape[1]), obs.data_ptr(),
                                         self._rew.data_ptr(), self._done.data_ptr(), self._info.data_ptr(),
                                         self._stream()), "msnake_step")
         return obs, self._rew, self._done, self._info
 
     def render_device(self, out=None):
-        obs = self._obs if out is None else out
+        obs = self._out(out)
         _capi.check(self._L.msnake_render(self._h, obs.data_ptr(), self._stream()), "msnake_render")
         return obs
 

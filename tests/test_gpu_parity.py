@@ -325,6 +325,16 @@ def test_errors_are_exceptions():
         env.step(np.zeros((3, 2), np.int32))
     with pytest.raises(RuntimeError, match="snakes"):
         env.set_state_words(0, np.zeros(8, np.int32))
+    acts = torch.zeros((4, 2), dtype=torch.int32, device="cuda")
+    for bad in (torch.empty((4, 12, 12, 3), dtype=torch.uint8, device="cuda"),      # too small: the kernel would overrun it
+                torch.empty((4, 12, 12, 9), dtype=torch.float32, device="cuda"),
+                torch.empty((4, 12, 12, 18), dtype=torch.uint8, device="cuda")[..., ::2],  # not contiguous
+                torch.empty((4, 12, 12, 9), dtype=torch.uint8)):                    # host memory
+        with pytest.raises(ValueError, match="out must be"):
+            env.step_device(acts, out=bad)
+        with pytest.raises(ValueError, match="out must be"):
+            env.reset_device(out=bad)
+    env.step_device(acts, out=torch.empty((4, 12, 12, 9), dtype=torch.uint8, device="cuda"))
     env.close()
     with pytest.raises(RuntimeError, match="handle"):
         env.step_device(torch.zeros((4, 2), dtype=torch.int32, device="cuda"))
