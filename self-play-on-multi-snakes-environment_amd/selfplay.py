@@ -329,7 +329,7 @@ class Runner:
             mb_rew[t] = rew
             self.dones = done.float()
             ep_r.append(torch.where(done.bool(), info[:, 0].view(torch.float32), torch.full_like(rew, float("nan"))))
-            ep_l.append(info[:, 1])
+            ep_l.append(info[:, 1].clone())  # `info` is the env's buffer: the next step overwrites it
         last_values = self.model.value(self.obs[..., 0:3])
         returns, _ = gae(mb_rew, mb_val, mb_done, last_values, self.dones, self.gamma, self.lam)
         # episode infos: one host sync per rollout instead of one per step

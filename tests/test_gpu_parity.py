@@ -356,6 +356,17 @@ def test_selfplay_ppo_rollouts_end_to_end():
     assert st["env_steps"] == 256 * 16 * 3 and st["errors"] == 0 and st["episodes"] > 0
     assert next(model.parameters()).is_cuda
     env.close()
+    # the episode infos a rollout reports are exactly what the env's own totals say (Monitor's r and l)
+    env = _mk(num_envs=128, dim=10, n_snakes=2, rules="snake_env", seed=4)
+    pol = selfplay.CnnPolicy((12, 12, 3)).to(env.device)
+    runner = selfplay.Runner(env, pol, [pol], 48, 0.99, 0.95)
+    env.stats(reset=True)
+    epinfos = runner.run()[-1]
+    st = env.stats()
+    assert st["episodes"] == len(epinfos) > 20
+    assert st["ep_len_sum"] == sum(e["l"] for e in epinfos)
+    assert st["ep_return_sum"] == round(sum(e["r"] for e in epinfos))
+    env.close()
 
 
 def test_vecenv_surface_like_the_reference_runner_uses_it():
