@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--train-steps", type=int, default=10_000_000)
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--obs-every", type=int, default=10)
+    ap.add_argument("--time-envs", type=int, default=0, help="also time msnake_step at this batch size under the policy")
     args = ap.parse_args()
     import torch
     import msnake
@@ -58,6 +59,42 @@ def main():
     for e in range(n):
         assert flat_to_state(env.get_state_words(e)) == ora.get_state(e), e
     assert env.stats()["errors"] == 0
+    if args.time_envs:
+        # what one msnake_step launch costs under the learnt policy's state distribution
+        m = args.time_envs
+        env2 = msnake.MultiSnakeVecEnv(m, dim=args.dim, n_snakes=ns, seed=5)
+        obs = env2.reset_device()
+        us = []
+        for t in range(400):
+            with torch.no_grad():
+                acts = torch.stack([model.step(obs[..., 3 * s:3 * s + 3])[0] for s in range(ns)], 1).to(torch.int32)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            obs, rew, done, info = env2.step_device(acts)
+            e1.record()
+            torch.cuda.synchronize()
+            if t >= 200:
+                us.append(e0.elapsed_time(e1) * 1e3)
+        st = env2.stats()
+        print(f"msnake_step under the learnt policy, {m} envs: median {np.median(us):.2f} us per launch "
+              f"(HIP events around single launches; mean episode length {st['ep_len_sum'] / max(1, st['episodes']):.0f})", flush=True)
+        env2.close()
+        env2 = msnake.MultiSnakeVecEnv(m, dim=args.dim, n_snakes=ns, seed=5)  # same method, random actions
+        env2.reset_device()
+        us = []
+        for t in range(400):
+            acts = torch.randint(0, 5, (m, ns), dtype=torch.int32, device="cuda")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            env2.step_device(acts)
+            e1.record()
+            torch.cuda.synchronize()
+            if t >= 200:
+                us.append(e0.elapsed_time(e1) * 1e3)
+        st = env2.stats()
+        print(f"msnake_step under uniform random actions, same method: median {np.median(us):.2f} us per launch "
+              f"(mean episode length {st['ep_len_sum'] / max(1, st['episodes']):.0f})", flush=True)
+        env2.close()
     print(f"POLICY SOAK OK: {n} envs x {args.steps} steps under the learnt policy, {episodes} episodes, "
           f"{eats} eat-steps of the main snake, longest sampled body {longest}")
 
