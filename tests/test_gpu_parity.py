@@ -531,6 +531,47 @@ def test_set_state_keeps_the_logging_totals():
     env.close()
 
 
+def _random_configs(k, seed):
+    rs = np.random.default_rng(seed)
+    out = []
+    for i in range(k):
+        rules = ["snake_env", "new_world", "adversarial"][i % 3]
+        ns = int(rs.integers(1, 5 if rules == "new_world" else 4))
+        nf = int(rs.integers(0, 12)) if rules == "new_world" else ns
+        out.append(dict(rules=rules, dim=int(rs.integers(2, 24)), n_snakes=ns, n_fruits=nf,
+                        max_steps=int(rs.choice([3, 17, 60, 2000])), auto_reset=bool(rs.integers(0, 2)),
+                        seed=int(rs.integers(0, 2**31)), env_id_base=int(rs.integers(0, 2**40)),
+                        num_envs=int(rs.integers(1, 90))))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _random_configs(30, 2024), ids=lambda c: f"{c['rules']}-{c['dim']}x{c['n_snakes']}x{c['n_fruits']}-"
+                                                                         f"T{c['max_steps']}-ar{int(c['auto_reset'])}-n{c['num_envs']}")
+def test_random_configurations_against_oracle(cfg):
+    """Thirty configurations drawn at random over every create() argument (rule set, grid size, snake
+    and fruit counts, step cap, auto-reset on/off, seed, env-id base, ragged batch sizes): reset + 80
+    steps, everything compared with the oracle, states at the end."""
+    from oracle.snake_oracle import Oracle
+    env = _mk(**cfg)
+    ora = Oracle(**cfg)
+    n, ns = cfg["num_envs"], cfg["n_snakes"]
+    assert np.array_equal(env.reset(), ora.reset())
+    rs = np.random.default_rng(cfg["seed"] % 1000)
+    for t in range(80):
+        act = rs.integers(-1, 6, (n, ns)).astype(np.int32)  # includes the invalid codes -1 and 5
+        obs, rew, done, infos = env.step(act)
+        o_obs, o_rew, o_done, o_ns, o_er, o_el = ora.step(act)
+        assert np.array_equal(obs, o_obs), t
+        assert np.array_equal(rew, o_rew) and np.array_equal(done, o_done.astype(bool)), t
+        assert np.array_equal(infos._ns, o_ns) and np.array_equal(infos._r, o_er) and np.array_equal(infos._l, o_el), t
+        if not cfg["auto_reset"] and t % 20 == 19:  # without auto-reset the caller resets, like a bare gym loop
+            assert np.array_equal(env.reset(), ora.reset())
+    for e in range(n):
+        assert _state(env, e) == ora.get_state(e), e
+    assert env.stats()["errors"] == 0
+    env.close()
+
+
 def test_step_is_hip_graph_capturable():
     """msnake_step does no allocation, copy or synchronisation, so a caller can capture it (with
     its policy) into a HIP graph; replays must equal direct launches."""
