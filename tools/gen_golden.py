@@ -694,6 +694,14 @@ def main():
     gen_tape("tape_N_10x10_2_raw", N, 10, 2, 4, seed=6, num_envs=32, steps=256, auto_reset=False)
     gen_tape("tape_A_10x10_2", A, 10, 2, 2, seed=0, num_envs=32, steps=192)
     gen_tape("tape_A_10x10_3", A, 10, 3, 3, seed=3, num_envs=32, steps=192)
+    # unusual shapes (the oracle must not be right only at the BASELINE sizes)
+    gen_tape("tape_S_5x5_3", S, 5, 3, 3, seed=8, num_envs=12, steps=96)
+    gen_tape("tape_S_3x3_2", S, 3, 2, 2, seed=9, num_envs=12, steps=96)
+    gen_tape("tape_S_23x23_1", S, 23, 1, 1, seed=10, num_envs=8, steps=64, action_width=3)
+    gen_tape("tape_N_6x6_4_f9", N, 6, 4, 9, seed=11, num_envs=12, steps=96)
+    gen_tape("tape_N_13x13_2_f0", N, 13, 2, 0, seed=12, num_envs=8, steps=64)
+    gen_tape("tape_A_6x6_3", A, 6, 3, 3, seed=13, num_envs=12, steps=96)
+    gen_tape("tape_A_19x19_1", A, 19, 1, 1, seed=14, num_envs=8, steps=64)
 
 
 if __name__ == "__main__":
