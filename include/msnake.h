@@ -142,7 +142,9 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
 /* Render the current state of every env without stepping (asynchronous). */
 int msnake_render(msnake_handle h, uint8_t* obs_dev, void* stream);
 
-/* Copy the aggregate statistics to the host (blocking on the handle's last stream). */
+/* Copy the aggregate statistics to the host (blocking on the handle's last stream).  episodes /
+ * ep_len_sum / ep_return_sum / errors are accumulated on the device; env_steps is counted on the host
+ * per API call, so replays of a captured HIP graph are not included in it. */
 int msnake_get_stats(msnake_handle h, msnake_stats* out, int32_t reset);
 
 /* Name of the step kernel (for profilers) and algorithmic HBM bytes per env-step. */
