@@ -4,23 +4,42 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment launches the N ranks itself (a
+child `python -m torch.distributed.run ... bench.py ...` started before anything touches the GPU; the
+parent only waits and exits with the child's code).
+
 A "step" is ONE lockstep step of every env of the batch = one msnake_step kernel launch through
 the C-ABI (include/msnake.h), actions already resident in HBM, observations / rewards / dones /
 info written to HBM.  Workload at every N: 4 096 envs per GPU, 19x19 grid, 3 snakes, snake_env
 rules, auto-reset on (BASELINE.json configs[2]; configs[3] = the same per-GPU shard on 8 GPUs), so
-scaling is weak.  Envs never communicate: ranks shard the global env ids with no data-path
-collective; RCCL is used once, after the timed region, to all-gather the episode statistics.
+scaling is weak.  Envs never communicate: ranks shard the global env ids (msnake.make_sharded) with
+no data-path collective; the one collective is msnake.gather_stats after the timed regions (RCCL).
+
+Timing ("warm-up, time K steps, repeats, median"): after W warm-up steps the K-step
+region is timed R = max(5, ceil(2048 / K)) times.  Every repeat is bracketed by barrier +
+torch.cuda.synchronize() on both sides and timed with HIP events recorded on the launch stream
+right around its K launches; per repeat the MAX over ranks is taken, and `value`, `ms_per_step` and
+`roofline` all come from the MEDIAN repeat -- one clock for all three, independent of K.  The host
+wall clock around the same region (it adds the launch latency of the first step and the wake-up
+after the final synchronize, a fixed 30-40 us per region) is reported as `wall_ms_per_step`.
 
 Prints ONE JSON line (rank 0).  Extra keys beside the driver's contract:
   roofline     : dominant kernel vs the HBM roofline (algorithmic bytes per launch from
-                 msnake_algorithmic_bytes_per_env_step() x envs, duration from HIP events on the
-                 launch stream over the timed region; PMC traffic from profiles/ when present)
+                 msnake_algorithmic_bytes_per_env_step() x envs, duration = the median above;
+                 `traffic` = PMC bytes per launch of the newest committed profiles/hbm_traffic_*.json,
+                 named in `traffic_source` -- a recorded counter pass of this command, not a live one)
+  rollout_tape : the same steps through the persistent msnake_rollout_tape launch, every step's
+                 observations going to their own slice of a T x 16.3 MB buffer (never `value`)
   cpu_baseline : the CPU oracle (oracle/snake_oracle.c, the parity-pinned port of the reference)
                  timed on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -33,6 +52,7 @@ if ROOT not in sys.path:
 ENVS_PER_GPU = 4096
 DIM, N_SNAKES = 19, 3
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+TAPE_STEPS = 256
 
 
 def cpu_quota():
@@ -78,15 +98,34 @@ def cpu_baseline(actions_host, seconds=12.0):
 
 
 def load_pmc_traffic():
-    """HBM bytes per launch from the newest committed PMC pass (profiles/hbm_traffic_*.json:
-    separate FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH doubled for gfx950), or None."""
+    """(HBM bytes per launch, source) from the newest committed PMC pass (profiles/hbm_traffic_*.json:
+    separate FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH doubled for gfx950), or (None, None)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "hbm_traffic_*.json")))
     try:
         with open(files[-1]) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+            d = json.load(f)
+        src = "profiles/" + os.path.basename(files[-1])
+        if d.get("recorded"):
+            src += f" (rocprofv3 --pmc passes recorded {d['recorded']}; not measured by this run)"
+        else:
+            src += " (recorded rocprofv3 --pmc passes; not measured by this run)"
+        return d.get("hbm_bytes_per_launch"), src
     except Exception:  # noqa: BLE001
-        return None
+        return None, None
+
+
+def self_launch(args):
+    """--gpus N > 1 without a torchrun environment: become the launcher.  Nothing in this process has
+    touched the GPU (torch is not even imported yet), the ranks are ordinary child processes."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -95,12 +134,16 @@ def main():
     ap.add_argument("--steps", type=int, default=2048)
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of the K-step region (default max(5, ceil(2048/K)))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--python-loop", action="store_true", help="issue launches from Python instead of msnake_step_tape")
     ap.add_argument("--no-rollout", action="store_true", help="skip the secondary msnake_rollout_tape leg (profiling)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + MSNAKE_BENCH_ONE_DEVICE=1 rehearses the N>1 path with every rank on cuda:0")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import msnake
@@ -126,11 +169,13 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
     n = args.envs_per_gpu
     K, Wm = args.steps, args.warmup
+    R = args.repeats if args.repeats > 0 else max(5, math.ceil(2048 / max(1, K)))
 
-    env = msnake.MultiSnakeVecEnv(n, dim=DIM, n_snakes=N_SNAKES, rules="snake_env", seed=0,
-                                  env_id_base=rank * n, device=dev)
+    # rank r owns the global env ids [r*n, (r+1)*n): the shipped sharding API, not a hand-rolled one
+    env = msnake.make_sharded(n * world, rank, world, device=dev, dim=DIM, n_snakes=N_SNAKES, rules="snake_env", seed=0)
+    assert env.num_envs == n and env.cfg.env_id_base == rank * n
     # synthetic input: uniform random actions in [0,5), one tape shared by the GPU and CPU runs
-    T = 256
+    T = TAPE_STEPS
     tape_h = np.random.default_rng(1234 + rank).integers(0, 5, (T, n, N_SNAKES)).astype(np.int32)
     tape = torch.from_numpy(tape_h).to(dev)
     env.reset_device()
@@ -153,91 +198,115 @@ def main():
                                                       env._stream()), "msnake_step_tape")
             k += m
 
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     run(Wm, 0)
     torch.cuda.synchronize()
     env.stats(reset=True)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run(K, Wm)
-    ev1.record()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    dev_ms, wall_ms = [], []
+    for r in range(R):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync_all()
+        t0 = time.perf_counter()
+        ev0.record()
+        run(K, Wm + r * K)
+        ev1.record()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dev_ms.append(ev0.elapsed_time(ev1))
+        wall_ms.append((t1 - t0) * 1e3)
 
     st = env.stats()
-    assert st["errors"] == 0 and st["env_steps"] == K * n, st
+    assert st["errors"] == 0 and st["env_steps"] == R * K * n, st
 
     # secondary figure: the same K steps through msnake_rollout_tape (ONE persistent launch per tape
     # chunk, env state kept in registers across steps).  Only usable when the actions of several
-    # steps exist up front, so it is reported beside the headline, not as it.
+    # steps exist up front, so it is reported beside the headline, not as it.  Every step's
+    # observations go to their own slice of a T-step buffer (T x 16.3 MB), so all of them reach HBM.
     rollout = None
     if rank == 0 and not args.python_loop and not args.no_rollout:
+        Tr = min(T, max(1, K))
+        S = H * Wd * C
+        obs_t = torch.empty((Tr, n, H, Wd, C), dtype=torch.uint8, device=dev)
+        rew_t = torch.empty((Tr, n), dtype=torch.float32, device=dev)
+        done_t = torch.empty((Tr, n), dtype=torch.uint8, device=dev)
+        info_t = torch.empty((Tr, n, 4), dtype=torch.int32, device=dev)
+
         def run_rollout(nsteps):
             k = 0
             while k < nsteps:
-                m = min(nsteps - k, T)
-                msnake._capi.check(L.msnake_rollout_tape(h, tape.data_ptr(), N_SNAKES, m, obs.data_ptr(), 0,
-                                                         rew.data_ptr(), done.data_ptr(), info.data_ptr(), 0,
+                m = min(nsteps - k, Tr)
+                msnake._capi.check(L.msnake_rollout_tape(h, tape.data_ptr(), N_SNAKES, m, obs_t.data_ptr(), n * S,
+                                                         rew_t.data_ptr(), done_t.data_ptr(), info_t.data_ptr(), n,
                                                          env._stream()), "msnake_rollout_tape")
                 k += m
-        run_rollout(Wm)
+        run_rollout(min(Wm, Tr))
         torch.cuda.synchronize()
-        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        r0.record()
-        run_rollout(K)
-        r1.record()
-        torch.cuda.synchronize()
-        rollout = r0.elapsed_time(r1) * 1e3 / K  # us per step
+        ro = []
+        for _ in range(5):
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            r0.record()
+            run_rollout(max(K, Tr))
+            r1.record()
+            torch.cuda.synchronize()
+            ro.append(r0.elapsed_time(r1) * 1e3 / max(K, Tr))  # us per step
+        rollout = statistics.median(ro)
         env.stats(reset=True)
-    # the only collective of the path: all-gather of the per-rank episode statistics (RCCL)
-    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # collectives run where the backend lives
-    rec = torch.tensor([st["episodes"], st["ep_len_sum"], st["ep_return_sum"], st["env_steps"]],
-                       dtype=torch.int64, device=cdev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        del obs_t
+
+    # the only collective of the path: all-gather of the per-rank episode statistics (RCCL on GPUs)
+    per_rank, total = msnake.gather_stats(st)
+    cdev = dev if (dist and args.backend == "nccl") else torch.device("cpu")  # collectives run where the backend lives
+    tmax = torch.tensor([dev_ms, wall_ms], dtype=torch.float64, device=cdev)
     if dist:
-        allrec = [torch.zeros_like(rec) for _ in range(world)]
-        dist.all_gather(allrec, rec)
-        rec = torch.stack(allrec).sum(0)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-    episodes, len_sum, ret_sum, steps_total = (int(x) for x in rec.tolist())
+    dev_ms, wall_ms = tmax[0].tolist(), tmax[1].tolist()
 
     if rank == 0:
-        value = steps_total / elapsed
+        assert len(per_rank) == world and total["env_steps"] == R * K * n * world, total
+        med_ms = statistics.median(dev_ms)
+        steps_per_region = K * n * world
+        value = steps_per_region / (med_ms * 1e-3)
         bytes_per_env_step = env.algorithmic_bytes_per_env_step()
         bytes_per_launch = bytes_per_env_step * n
-        launch_us = dev_ms * 1e3 / K
+        launch_us = med_ms * 1e3 / K
         achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
+        traffic, traffic_src = load_pmc_traffic()
         out = {
             "metric": "env-steps/sec (agent·step) at 4 096×19×19×3-snake, 1/2/4/8 GPU + CPU ref",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(elapsed * 1e3 / K, 6), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(med_ms / K, 6), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{n} envs/GPU x {DIM}x{DIM} x {N_SNAKES} snakes, snake_env rules, auto-reset, "
                                    f"native {H}x{Wd}x{C} uint8 obs, uniform random actions (BASELINE configs[2]"
                                    + ("/[3]" if world > 1 else "") + ")",
                        "envs_total": n * world, "agent_steps_per_s": round(value * N_SNAKES, 1),
                        "launch": "python per-step" if args.python_loop else "msnake_step_tape (C loop, 1 launch/step)",
-                       "mean_episode_len": round(len_sum / max(1, episodes), 2),
-                       "mean_episode_return": round(ret_sum / max(1, episodes), 3)},
+                       "mean_episode_len": round(total["mean_ep_len"], 2),
+                       "mean_episode_return": round(total["mean_ep_return"], 3),
+                       "env_steps_per_rank": [p["env_steps"] for p in per_rank]},
+            "timing": {"clock": "HIP events on the launch stream around each K-step region, max over ranks, median of repeats",
+                       "repeats": R, "repeats_us_per_step": [round(x * 1e3 / K, 3) for x in dev_ms],
+                       "wall_ms_per_step": round(statistics.median(wall_ms) / K, 6)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": env.kernel_name(), "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if rollout is not None:
             out["rollout_tape"] = {
-                "what": "same steps via msnake_rollout_tape: one persistent launch per 256-step tape chunk",
+                "what": f"same steps via msnake_rollout_tape: one persistent launch per {Tr}-step tape chunk, "
+                        f"observations of every step stored to their own slice of a {Tr} x {n * S / 1e6:.1f} MB buffer",
                 "us_per_step": round(rollout, 3), "env_steps_per_s": round(n / rollout * 1e6, 1),
                 "algorithmic_GBs": round(bytes_per_launch / rollout / 1e3, 1),
-                "frac_of_hbm_peak": round(bytes_per_launch / rollout / 1e3 / HBM_PEAK_GBS, 4)}
+                "algorithmic_frac_of_hbm_peak": round(bytes_per_launch / rollout / 1e3 / HBM_PEAK_GBS, 4)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(tape_h)
         print(json.dumps(out), flush=True)

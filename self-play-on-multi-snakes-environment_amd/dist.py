@@ -30,8 +30,13 @@ def gather_stats(local, device=None, group=None):
     import torch
     import torch.distributed as dist
 
-    rec = torch.tensor([int(local[k]) for k in STAT_KEYS], dtype=torch.int64, device=device or "cpu")
-    if dist.is_available() and dist.is_initialized():
+    live = dist.is_available() and dist.is_initialized()
+    if device is None:
+        # RCCL ("nccl") moves device tensors only; gloo moves host tensors
+        on_gpu = live and "nccl" in str(dist.get_backend(group)) and torch.cuda.is_available()
+        device = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    rec = torch.tensor([int(local[k]) for k in STAT_KEYS], dtype=torch.int64, device=device)
+    if live:
         world = dist.get_world_size(group)
         out = [torch.zeros_like(rec) for _ in range(world)]
         dist.all_gather(out, rec, group=group)
@@ -44,12 +49,18 @@ def gather_stats(local, device=None, group=None):
     return per_rank, total
 
 
-def make_sharded(total_envs, rank=None, world=None, **kw):
-    """MultiSnakeVecEnv for this rank's shard of `total_envs` global envs (env ids stay global)."""
+def make_sharded(total_envs, rank=None, world=None, device=None, **kw):
+    """MultiSnakeVecEnv for this rank's shard of `total_envs` global envs (env ids stay global).
+
+    rank / world default to torchrun's RANK / WORLD_SIZE; the device defaults to cuda:LOCAL_RANK
+    (one process per GPU), so a rank that never called torch.cuda.set_device still lands on its own
+    card.  The handle and every buffer of the env live on that device."""
     import os
     from .vec_env import MultiSnakeVecEnv
 
     rank = int(os.environ.get("RANK", "0")) if rank is None else rank
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    if device is None:
+        device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
     start, count = shard_range(total_envs, rank, world)
-    return MultiSnakeVecEnv(count, env_id_base=start, **kw)
+    return MultiSnakeVecEnv(count, env_id_base=start, device=device, **kw)

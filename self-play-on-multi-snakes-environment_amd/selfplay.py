@@ -145,17 +145,44 @@ def explained_variance(ypred, y):
 
 
 # ----------------------------------------------------------------------------- opponent pool, logs
-class OpponentPool:
-    """Ring of past policies (config.py:13-14: save every 50 updates, keep <= 1000)."""
+def save_weights(model, path):
+    """Model.save (ppo_multi_agent.py:112-114: joblib.dump of the parameter list): here a plain
+    state_dict of tensors, written atomically, loadable with torch.load(weights_only=True)."""
+    tmp = path + ".tmp"
+    torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, tmp)
+    os.replace(tmp, path)
 
-    def __init__(self, max_saved=1000):
+
+def load_weights(model, path):
+    """Model.load (ppo_multi_agent.py:124-132).  weights_only: nothing in the file is executed."""
+    model.load_state_dict(torch.load(path, map_location=next(model.parameters()).device, weights_only=True))
+
+
+class OpponentPool:
+    """Ring of past policies (config.py:13-14: save every 50 updates, keep <= 1000).  Held in device
+    memory; with `directory` every save is also written through to `opponent<which>_<idx>.pt`
+    (utils.py:57-64 names opponent1_<x>.pkl / opponent2_<x>.pkl) so a later run can restore the pool."""
+
+    def __init__(self, max_saved=1000, directory=None, which=1):
         self.max_saved, self.slots, self.idx, self.num = max_saved, {}, 0, 0
+        self.directory, self.which = directory, which
+
+    def file(self, idx):
+        return os.path.join(self.directory, f"opponent{self.which}_{idx}.pt")
 
     def save(self, model):
         self.slots[self.idx] = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        if self.directory:
+            save_weights(model, self.file(self.idx))
         self.idx += 1
         self.num = max(self.idx, self.num)
         self.idx %= self.max_saved
+
+    def restore(self, device, idx, num):
+        """Reload slots 0..num-1 from `directory` and continue writing at `idx` (resume)."""
+        for i in range(num):
+            self.slots[i] = torch.load(self.file(i), map_location=device, weights_only=True)
+        self.idx, self.num = idx, num
 
     def load_random(self, model, rng=random):
         sel = rng.randint(0, max(self.num - 1, 0))  # ppo_multi_agent.py:315
@@ -344,18 +371,50 @@ class Runner:
 def learn(env, nsteps=64, total_timesteps=int(1e6), ent_coef=0.01, lr=lambda f: f * 2.5e-4, vf_coef=0.5,
           max_grad_norm=0.5, gamma=0.99, lam=0.95, log_interval=1, nminibatches=8, noptepochs=4,
           cliprange=lambda f: f * 0.1, opponent_save_interval=50, max_saved_opponents=1000, csv_path=None,
-          monitor_path=None, seed=0, log_fn=print, amp_dtype=None, json_path=None, tb_dir=None):
-    """ppo_multi_agent.py:231-404 (hyper-parameters of test/ppo1_single_test.py:42-47 as defaults)."""
+          monitor_path=None, seed=0, log_fn=print, amp_dtype=None, json_path=None, tb_dir=None,
+          save_dir=None, save_interval=0, load_path=None, resume=False):
+    """ppo_multi_agent.py:231-404 (hyper-parameters of test/ppo1_single_test.py:42-47 as defaults).
+
+    Checkpoints (ppo_multi_agent.py:112-133, 296-306, 349-364, 392-404), weights only, under `save_dir`
+    (the reference's saved_models/<expr>/): the opponent pool as opponent<i>_<idx>.pt every
+    `opponent_save_interval` updates, snake_model_num<N>_<k>.pt at update 1 and every `save_interval`
+    updates, highscore_model.pt whenever the 100-episode mean passes the next integer above 5 (single
+    snake only, :398-401), snake_model_num<N>.pt at the end.  `load_path` initialises the learner and
+    its opponents from a weights file (the reference's `baseline_file`, :264-275).  `resume=True`
+    continues a run from save_dir/trainer_state.pt (weights, Adam moments, update counter, pool
+    positions -- the reference cannot do this; schedules continue where they stopped)."""
     torch.manual_seed(seed); random.seed(seed)
     dev = env.device
     n_snakes = env.n_snakes
     H, W, _ = env.obs_shape
     model = CnnPolicy((H, W, 3), amp_dtype=amp_dtype).to(dev)
     opponents = [CnnPolicy((H, W, 3), amp_dtype=amp_dtype).to(dev) for _ in range(n_snakes - 1)]
-    pools = [OpponentPool(max_saved_opponents) for _ in opponents]
-    for pool in pools:
-        pool.save(model)
+    if save_dir:
+        os.makedirs(save_dir, exist_ok=True)
+    if load_path:
+        for m in [model] + opponents:
+            load_weights(m, load_path)
+    pools = [OpponentPool(max_saved_opponents, save_dir, i + 1) for i in range(len(opponents))]
     opt = torch.optim.Adam(model.parameters(), lr=lr(1.0), eps=1e-5)
+    first_update, model_idx, next_highscore = 1, 0, 5
+    state_file = os.path.join(save_dir, "trainer_state.pt") if save_dir else None
+    if resume and state_file and os.path.exists(state_file):
+        ts = torch.load(state_file, map_location=dev, weights_only=True)
+        model.load_state_dict(ts["model"])
+        opt.load_state_dict(ts["optimizer"])
+        first_update, model_idx, next_highscore = ts["update"] + 1, ts["model_idx"], ts["next_highscore"]
+        for pool, (idx, num) in zip(pools, ts["pools"]):
+            pool.restore(dev, idx, num)
+    else:
+        for pool in pools:
+            pool.save(model)
+
+    def save_trainer_state(update):
+        tmp = state_file + ".tmp"
+        torch.save({"model": model.state_dict(), "optimizer": opt.state_dict(), "update": update,
+                    "model_idx": model_idx, "next_highscore": next_highscore,
+                    "pools": [(p.idx, p.num) for p in pools]}, tmp)
+        os.replace(tmp, state_file)
     runner = Runner(env, model, opponents, nsteps, gamma, lam)
     nbatch = env.num_envs * nsteps
     nbatch_train = nbatch // nminibatches
@@ -369,7 +428,7 @@ def learn(env, nsteps=64, total_timesteps=int(1e6), ent_coef=0.01, lr=lambda f: 
         sinks.append(TensorBoardLogger(tb_dir))
     mon = MonitorCSV(monitor_path, "msnake") if monitor_path else None
     history, tfirst = [], time.time()
-    for update in range(1, nupdates + 1):
+    for update in range(first_update, nupdates + 1):
         for opp, pool in zip(opponents, pools):
             pool.load_random(opp)
         tstart = time.time()
@@ -416,6 +475,18 @@ def learn(env, nsteps=64, total_timesteps=int(1e6), ent_coef=0.01, lr=lambda f: 
                 sink.writekvs(kvs)
             if log_fn:
                 log_fn(" ".join(f"{k}={v:.4g}" if isinstance(v, float) else f"{k}={v}" for k, v in kvs.items()))
+        if save_dir:
+            if save_interval and (update % save_interval == 0 or update == 1):  # ppo_multi_agent.py:392-394
+                save_weights(model, os.path.join(save_dir, f"snake_model_num{n_snakes}_{model_idx}.pt"))
+                model_idx += 1
+                save_trainer_state(update)
+            eprew_now = float(np.mean([e["r"] for e in epinfobuf])) if epinfobuf else float("nan")
+            if n_snakes == 1 and eprew_now > next_highscore:                    # ppo_multi_agent.py:397-401
+                next_highscore += 1
+                save_weights(model, os.path.join(save_dir, "highscore_model.pt"))
+    if save_dir:
+        save_weights(model, os.path.join(save_dir, f"snake_model_num{n_snakes}.pt"))  # ppo_multi_agent.py:402
+        save_trainer_state(nupdates)
     for sink in sinks:
         sink.close()
     if mon:

@@ -132,3 +132,44 @@ def test_one_hip_runtime_per_process_whatever_the_import_order():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split()[0] == "1", out.stdout
+
+
+def test_make_sharded_defaults_to_the_local_rank_device(monkeypatch):
+    """One process per GPU under torchrun: rank r's shard must land on cuda:LOCAL_RANK without the caller
+    having called torch.cuda.set_device, and keep global env ids."""
+    seen = {}
+
+    class FakeEnv:
+        def __init__(self, num_envs, **kw):
+            seen.update(num_envs=num_envs, **kw)
+
+    monkeypatch.setattr(msnake.vec_env, "MultiSnakeVecEnv", FakeEnv)
+    monkeypatch.setenv("RANK", "5")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    msnake.make_sharded(32768, dim=19, n_snakes=3)
+    assert seen == dict(num_envs=4096, env_id_base=5 * 4096, device="cuda:5", dim=19, n_snakes=3)
+    msnake.make_sharded(10, rank=1, world=3, device="cuda:0")
+    assert seen["num_envs"] == 3 and seen["env_id_base"] == 4 and seen["device"] == "cuda:0"
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` without a torchrun environment starts the N ranks itself, before
+    importing torch, and hands the child's exit code back."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 7)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 7
+    cmd, env = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

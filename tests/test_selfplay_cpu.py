@@ -151,3 +151,83 @@ def test_json_and_tensorboard_sinks_round_trip(tmp_path):
             d = dict(fields(v))
             vals[d[1].decode()] = d[2]
         assert vals == {k: float(np.float32(v)) for k, v in row.items()}
+
+
+class _FakeEnv:
+    """CPU stand-in with the device-side surface learn() uses (reset_device / step_device)."""
+
+    def __init__(self, n=8, n_snakes=2, seed=0):
+        self.num_envs, self.n_snakes, self.obs_shape, self.device = n, n_snakes, (12, 12, 9), torch.device("cpu")
+        self.g = torch.Generator().manual_seed(seed)
+        self.len = torch.zeros(n, dtype=torch.int32)
+
+    def reset_device(self):
+        return torch.randint(0, 256, (self.num_envs,) + self.obs_shape, dtype=torch.uint8, generator=self.g)
+
+    def step_device(self, actions):
+        assert actions.shape == (self.num_envs, self.n_snakes) and actions.dtype == torch.int32
+        self.len += 1
+        done = (torch.rand(self.num_envs, generator=self.g) < 0.3)
+        rew = torch.randint(0, 2, (self.num_envs,), generator=self.g).float()
+        info = torch.zeros((self.num_envs, 4), dtype=torch.int32)
+        info[:, 0] = torch.full((self.num_envs,), 7.0).view(torch.int32)
+        info[:, 1] = self.len
+        self.len = torch.where(done, torch.zeros_like(self.len), self.len)
+        return self.reset_device(), rew, done.to(torch.uint8), info
+
+
+def test_checkpoints_save_load_and_resume(tmp_path):
+    """ppo_multi_agent.py:112-133 (save/load), :296-306 and :349-364 (opponent files), :392-404 (periodic,
+    highscore and final saves) -- as weights-only files -- plus resuming a run from trainer_state.pt."""
+    import os
+    d = str(tmp_path / "ckpt")
+    kw = dict(nsteps=4, total_timesteps=8 * 4 * 6, nminibatches=2, noptepochs=1, opponent_save_interval=2, log_fn=None)
+    model, hist = selfplay.learn(_FakeEnv(), save_dir=d, save_interval=2, **kw)
+    files = set(os.listdir(d))
+    assert {"opponent1_0.pt", "opponent1_1.pt", "opponent1_2.pt", "opponent1_3.pt", "snake_model_num2_0.pt",
+            "snake_model_num2_1.pt", "snake_model_num2_2.pt", "snake_model_num2_3.pt", "snake_model_num2.pt",
+            "trainer_state.pt"} <= files and "highscore_model.pt" not in files
+    fresh = selfplay.CnnPolicy((12, 12, 3))
+    selfplay.load_weights(fresh, os.path.join(d, "snake_model_num2.pt"))
+    for a, b in zip(model.state_dict().values(), fresh.state_dict().values()):
+        assert torch.equal(a, b)
+    # the files hold tensors only: the safe loader is enough
+    ts = torch.load(os.path.join(d, "trainer_state.pt"), weights_only=True)
+    assert ts["update"] == 6 and ts["pools"] == [(4, 4)] and ts["model_idx"] == 4
+    assert int(ts["optimizer"]["state"][0]["step"]) == 6 * 2
+
+    # load_path: learner and opponent start from the file (the reference's baseline_file)
+    m2, _ = selfplay.learn(_FakeEnv(), load_path=os.path.join(d, "snake_model_num2_0.pt"),
+                           **dict(kw, total_timesteps=8 * 4, lr=lambda f: 0.0))
+    first = torch.load(os.path.join(d, "snake_model_num2_0.pt"), weights_only=True)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, first[k]), k
+
+    # an interrupted run resumes from its last trainer_state (update 2) and finishes updates 3..6
+    d2 = str(tmp_path / "ckpt2")
+
+    class Stop(Exception):
+        pass
+
+    seen = []
+
+    def stop_at_3(line):
+        seen.append(line)
+        if "nupdates=3" in line:
+            raise Stop
+
+    try:
+        selfplay.learn(_FakeEnv(), save_dir=d2, save_interval=2, **dict(kw, log_fn=stop_at_3))
+        assert False, "should have been interrupted"
+    except Stop:
+        pass
+    assert torch.load(os.path.join(d2, "trainer_state.pt"), weights_only=True)["update"] == 2
+    _, hist2 = selfplay.learn(_FakeEnv(seed=1), save_dir=d2, save_interval=2, resume=True, **kw)
+    assert [h["nupdates"] for h in hist2] == [3, 4, 5, 6] and hist2[-1]["num_opponents"] == 4
+    ts2 = torch.load(os.path.join(d2, "trainer_state.pt"), weights_only=True)
+    assert ts2["update"] == 6 and int(ts2["optimizer"]["state"][0]["step"]) == 6 * 2 and ts2["pools"] == [(4, 4)]
+
+    # single snake: highscore_model.pt once the 100-episode mean (7.0 here) passes 5 (ppo_multi_agent.py:397-401)
+    d3 = str(tmp_path / "ckpt3")
+    selfplay.learn(_FakeEnv(n_snakes=1), save_dir=d3, **dict(kw, total_timesteps=8 * 4 * 2))
+    assert "highscore_model.pt" in os.listdir(d3) and not any(f.startswith("opponent") for f in os.listdir(d3))

@@ -23,6 +23,10 @@ def main():
     ap.add_argument("--monitor", default=None)
     ap.add_argument("--json", default=None, help="progress.json (baselines JSON log format)")
     ap.add_argument("--tensorboard", default=None, help="directory for a TensorBoard events file")
+    ap.add_argument("--save", default=None, metavar="DIR", help="checkpoint directory (the reference's saved_models/<expr>/)")
+    ap.add_argument("--save-interval", type=int, default=0, help="also save snake_model_num<N>_<k>.pt every this many updates")
+    ap.add_argument("--load", default=None, metavar="FILE", help="initialise learner and opponents from a weights file")
+    ap.add_argument("--resume", action="store_true", help="continue from <--save DIR>/trainer_state.pt")
     args = ap.parse_args()
     import torch
     import msnake
@@ -31,7 +35,9 @@ def main():
     env = msnake.MultiSnakeVecEnv(args.envs, dim=args.dim, n_snakes=args.snakes, rules=args.rules, seed=0,
                                   obs_scale=args.scale)
     selfplay.learn(env, nsteps=args.nsteps, total_timesteps=args.timesteps, csv_path=args.csv,
-                   monitor_path=args.monitor, json_path=args.json, tb_dir=args.tensorboard, amp_dtype=torch.bfloat16 if args.bf16 else None)
+                   monitor_path=args.monitor, json_path=args.json, tb_dir=args.tensorboard,
+                   amp_dtype=torch.bfloat16 if args.bf16 else None, save_dir=args.save, save_interval=args.save_interval,
+                   load_path=args.load, resume=args.resume)
     print(env.stats())
     env.close()
 
