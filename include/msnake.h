@@ -22,8 +22,9 @@
  *                      (envs/snake_adversarial_env.py:166-201), including the observation render
  *                      get_multi_snake_ob (snake_multiple_test.py:35-58,93-95)
  *   msnake_destroy  <- SubprocVecEnv.close (subproc_vec_env.py:73-83)
- *   msnake_get_state / msnake_set_state: no reference counterpart (env state is never
- *                      checkpointed there); used by the parity tests to install hand-built states.
+ *   msnake_get_state / msnake_set_state / msnake_get_state_all / msnake_set_state_all: no reference
+ *                      counterpart (env state is never checkpointed there); used by
+ *                      the parity tests to install hand-built states and by callers to checkpoint.
  *   msnake_get_stats <- the epinfobuf aggregation in ppo_multi_agent.py:288,331,366-390
  *
  * RNG contract (shared with oracle/ and tests/golden): draw i of global env g is word (i & 3) of
@@ -41,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MSNAKE_ABI_VERSION 1
+#define MSNAKE_ABI_VERSION 2
 
 /* rule sets = the reference's gym ids (gym-snake/gym_snake/__init__.py:11-26) */
 #define MSNAKE_RULES_SNAKE_ENV 0   /* snake-multiple-test-v0  : SnakeEnv            */
@@ -83,7 +84,10 @@ typedef struct msnake_info {
     int32_t flags;      /* bit 0: done                            */
 } msnake_info;
 
-/* aggregate episode statistics since create (or since the last msnake_get_stats(reset=1)) */
+/* aggregate episode statistics since create (or since the last msnake_get_stats(reset=1)).  An
+ * episode is counted on the step it ends; with auto_reset = 0 a finished env keeps returning
+ * done = 1 until msnake_reset, but is counted once.  Per env the totals are kept as 32-bit episode
+ * count / 64-bit length sum / 32-bit signed return sum between two msnake_get_stats(reset=1) calls. */
 typedef struct msnake_stats {
     int64_t episodes;      /* number of finished episodes                 */
     int64_t ep_len_sum;    /* sum of their lengths                        */
@@ -111,7 +115,9 @@ int msnake_reset(msnake_handle h, uint8_t* obs_dev, void* stream);
 /* One lockstep step of every env.  actions_dev: int32 [num_envs][action_stride], entry s of a
  * row is snake s's action in {0..4}; action_stride >= n_snakes, surplus entries are ignored
  * (ppo_multi_agent.py:41-44 always sends tuples of 2 or 3).  rew_dev float32[num_envs],
- * done_dev uint8[num_envs], info_dev msnake_info[num_envs] (may be NULL).  Asynchronous. */
+ * done_dev uint8[num_envs], info_dev msnake_info[num_envs] (may be NULL).  obs_dev may be NULL (no
+ * render); it needs no alignment at obs_scale 1 and 4-byte alignment at obs_scale 4 / 7
+ * (MSNAKE_E_ALIGN otherwise).  Asynchronous. */
 int msnake_step(msnake_handle h, const int32_t* actions_dev, int32_t action_stride, uint8_t* obs_dev,
                 float* rew_dev, uint8_t* done_dev, msnake_info* info_dev, void* stream);
 
@@ -139,15 +145,31 @@ int msnake_rollout_tape(msnake_handle h, const int32_t* actions_dev, int32_t act
 int msnake_get_state(msnake_handle h, int32_t env, int32_t* words, int32_t cap);
 int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t n);
 
+/* The same canonical words for EVERY env of the handle in one host buffer (blocking; checkpoints):
+ * one packing kernel on the device and one copy, instead of num_envs round trips.  Layout of `buf`:
+ *   { uint32 magic "MSST", uint32 version, int32 num_envs, dim, n_snakes, n_fruits, rules, reserved,
+ *     uint64 total_words }  (40 bytes)
+ *   uint64 offsets[num_envs + 1]   word offset of env e's state inside `words`
+ *   int32  words[total_words]      env e's words = words[offsets[e] .. offsets[e+1]), layout as above
+ * msnake_get_state_all returns the number of bytes needed; it writes them only if buf != NULL and
+ * cap_bytes suffices (call once with NULL to size the buffer).  msnake_set_state_all checks the
+ * blob against the handle's configuration and every env's words like msnake_set_state does; envs
+ * with malformed words are left untouched and the call fails with MSNAKE_E_STATE.  The per-env
+ * logging totals (msnake_get_stats) are not part of the canonical state and are kept. */
+int64_t msnake_get_state_all(msnake_handle h, void* buf, size_t cap_bytes);
+int msnake_set_state_all(msnake_handle h, const void* buf, size_t bytes);
+
 /* Render the current state of every env without stepping (asynchronous). */
 int msnake_render(msnake_handle h, uint8_t* obs_dev, void* stream);
 
-/* Copy the aggregate statistics to the host (blocking on the handle's last stream).  episodes /
- * ep_len_sum / ep_return_sum / errors are accumulated on the device; env_steps is counted on the host
- * per API call, so replays of a captured HIP graph are not included in it. */
+/* Copy the aggregate statistics to the host.  Blocking: waits for the device (every step issued so
+ * far, on any stream) before it sums the per-env totals.  episodes / ep_len_sum / ep_return_sum /
+ * errors are accumulated on the device; env_steps is counted on the host per API call, so replays
+ * of a captured HIP graph are not included in it. */
 int msnake_get_stats(msnake_handle h, msnake_stats* out, int32_t reset);
 
-/* Name of the step kernel (for profilers) and algorithmic HBM bytes per env-step. */
+/* Name of the step kernel (for profilers; the string is owned by the handle and lives until
+ * msnake_destroy) and algorithmic HBM bytes per env-step. */
 const char* msnake_kernel_name(msnake_handle h);
 int64_t msnake_algorithmic_bytes_per_env_step(msnake_handle h);
 

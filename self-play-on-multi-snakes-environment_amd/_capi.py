@@ -16,6 +16,7 @@ RULE_NAMES = {v: k for k, v in RULES.items()}
 SYMBOLS = [
     "msnake_abi_version", "msnake_last_error", "msnake_create", "msnake_destroy", "msnake_obs_shape",
     "msnake_reset", "msnake_step", "msnake_step_tape", "msnake_rollout_tape", "msnake_get_state", "msnake_set_state",
+    "msnake_get_state_all", "msnake_set_state_all",
     "msnake_render", "msnake_get_stats", "msnake_kernel_name", "msnake_algorithmic_bytes_per_env_step",
 ]
 
@@ -64,13 +65,17 @@ def load():
     L.msnake_rollout_tape.argtypes = L.msnake_step_tape.argtypes
     L.msnake_get_state.argtypes = [vp, i32, vp, i32]
     L.msnake_set_state.argtypes = [vp, i32, vp, i32]
+    L.msnake_get_state_all.argtypes = [vp, vp, ctypes.c_size_t]
+    L.msnake_get_state_all.restype = ctypes.c_int64
+    L.msnake_set_state_all.argtypes = [vp, vp, ctypes.c_size_t]
     L.msnake_get_stats.argtypes = [vp, ctypes.POINTER(MsnakeStats), i32]
     L.msnake_kernel_name.argtypes = [vp]
     L.msnake_kernel_name.restype = ctypes.c_char_p
     L.msnake_algorithmic_bytes_per_env_step.argtypes = [vp]
     L.msnake_algorithmic_bytes_per_env_step.restype = ctypes.c_int64
     for name in ("msnake_create", "msnake_destroy", "msnake_obs_shape", "msnake_reset", "msnake_render",
-                 "msnake_step", "msnake_step_tape", "msnake_rollout_tape", "msnake_get_state", "msnake_set_state", "msnake_get_stats"):
+                 "msnake_step", "msnake_step_tape", "msnake_rollout_tape", "msnake_get_state", "msnake_set_state", "msnake_set_state_all",
+                 "msnake_get_stats"):
         getattr(L, name).restype = ctypes.c_int
     _lib = L
     return L

@@ -1,7 +1,8 @@
 // msnake_capi.hip -- the C-ABI of include/msnake.h over the HIP kernels.  Host-side glue only:
 // argument checks, HBM allocation of the per-env state, the background image, launches, and the
-// (blocking, test/checkpoint-path) canonical state import/export.  No CPU fallback: without a HIP
-// device every entry point fails with MSNAKE_E_NOGPU / MSNAKE_E_HIP.
+// (blocking, test/checkpoint-path) canonical state import/export, whose packing itself runs on the
+// device.  No CPU fallback: without a HIP device every entry point fails with MSNAKE_E_NOGPU /
+// MSNAKE_E_HIP.
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -52,10 +53,12 @@ struct msnake_env {
     msnake_config cfg;
     msnake::StepParams p;  // configuration + state pointers; i/o pointers filled per call
     int epb;               // envs per workgroup
-    hipStream_t last_stream;
     int64_t env_steps;
     void* d_state;
     void* d_stats;
+    void* d_scratch;       // per-env state import/export staging (grown on demand)
+    size_t scratch_bytes;
+    char kname[64];
 };
 
 namespace {
@@ -65,14 +68,26 @@ int check(msnake_handle h) {
     return MSNAKE_OK;
 }
 
-int vel_code(int v0, int v1) {
-    if (v0 == 1 && v1 == 0) return 1;
-    if (v0 == 0 && v1 == 1) return 2;
-    if (v0 == -1 && v1 == 0) return 3;
-    if (v0 == 0 && v1 == -1) return 4;
-    return 0;
+int ensure_scratch(msnake_env* h, size_t bytes) {
+    if (bytes <= h->scratch_bytes) return MSNAKE_OK;
+    if (h->d_scratch) (void)hipFree(h->d_scratch);
+    h->d_scratch = nullptr; h->scratch_bytes = 0;
+    hipError_t e = hipMalloc(&h->d_scratch, bytes);
+    if (e != hipSuccess) return fail(MSNAKE_E_HIP, "allocating %zu bytes of state staging failed: %s", bytes, hipGetErrorString(e));
+    h->scratch_bytes = bytes;
+    return MSNAKE_OK;
 }
-const int kVel0[5] = {0, 1, 0, -1, 0}, kVel1[5] = {0, 0, 1, 0, -1};
+
+const char* state_reason(uint32_t code) {
+    switch (code) {
+        case 1: return "state buffer too short / truncated";
+        case 2: return "snake count differs from the handle's";
+        case 3: return "fruit count differs from the handle's (or exceeds the fruit-list capacity)";
+        case 4: return "a cell lies outside [-1, dim]";
+        case 5: return "a body length is outside [0, capacity]";
+        default: return "malformed state";
+    }
+}
 
 }  // namespace
 
@@ -197,6 +212,11 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
         const int v = atoi(epb);
         if (v >= 1 && v <= h->epb) h->epb = v;
     }
+    // record_policy: snake_env / adversarial steps can run on the first 128 bytes of the 256-byte
+    // record; the upper half only parks Philox draws for the waves that respawn or reset, which pays
+    // while a launch is latency bound (<= 8 192 envs) and is pure traffic above
+    p.short_rec = (cfg->rules != MSNAKE_RULES_NEW_WORLD && p.nenv > 8192) ? 1 : 0;
+    if (const char* sr = getenv("MSNAKE_SHORT_REC")) p.short_rec = (cfg->rules != MSNAKE_RULES_NEW_WORLD && atoi(sr)) ? 1 : 0;
     // obs_store_policy: should the observation stores carry the nt (streaming) hint?  Measured on
     // MI355X with the native 16-byte-per-lane copy-out (tools/kbench.py, MSNAKE_NT=0/1), per launch:
     //   <= 32 MiB of observations (<= 8 192 envs at 19x19x3; fits the 8 L2s): 2-3 % faster with nt
@@ -210,8 +230,11 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
         p.rest.stream_obs = (p.obs_scale == 1 && (obs_mib <= 32.0 || obs_mib >= 192.0)) ? 1u : 0u;
     }
     if (const char* nt = getenv("MSNAKE_NT")) p.rest.stream_obs = atoi(nt) ? 1u : 0u;  // experiment knob
+#ifdef MSNAKE_DBG_STAGES  // diagnostic builds only (tools/stamp_profile.py): never in the shipped library
     if (const char* dbg = getenv("MSNAKE_DBG_STAGE")) p.rest.dbg_stage = (uint32_t)atoi(dbg);
     if (const char* dbg = getenv("MSNAKE_DBG_BUF")) p.rest.dbg_buf = reinterpret_cast<unsigned long long*>(strtoull(dbg, nullptr, 0));
+#endif
+    msnake::step_kernel_name(cfg->rules, cfg->n_snakes, cfg->obs_scale, h->kname, sizeof(h->kname));
     h->magic = kMagic;
     *out = h;
     return MSNAKE_OK;
@@ -222,6 +245,7 @@ int msnake_destroy(msnake_handle h) {
     DeviceGuard guard(h->cfg.device);
     (void)hipDeviceSynchronize();
     (void)hipFree(h->d_state); (void)hipFree(h->d_stats);
+    if (h->d_scratch) (void)hipFree(h->d_scratch);
     h->magic = 0;
     free(h);
     return MSNAKE_OK;
@@ -242,9 +266,10 @@ static int launch(msnake_handle h, int mode, const int32_t* actions, int32_t act
     p.obs = obs; p.rest.rew = rew; p.rest.done = done; p.rest.info = info;
     DeviceGuard guard(h->cfg.device);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (obs && p.obs_scale > 1 && ((uintptr_t)obs & 3))  // the fused x4 / x7 copy-out stores dwords
+        return fail(MSNAKE_E_ALIGN, "obs_dev must be 4-byte aligned when obs_scale > 1");
     hipError_t e = msnake::launch_step(p, h->cfg.rules, mode, h->epb, s);
     if (e != hipSuccess) return fail(MSNAKE_E_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-    h->last_stream = s;
     return MSNAKE_OK;
 }
 
@@ -304,155 +329,149 @@ int msnake_rollout_tape(msnake_handle h, const int32_t* actions_dev, int32_t act
     p.rest.n_steps = n_steps;
     p.rest.obs_step_stride = obs_step_stride;
     p.rest.scalar_step_stride = scalar_step_stride;
+    if (obs_dev && p.obs_scale > 1 && (((uintptr_t)obs_dev | obs_step_stride) & 3))
+        return fail(MSNAKE_E_ALIGN, "obs_dev and obs_step_stride must be multiples of 4 when obs_scale > 1");
     DeviceGuard guard(h->cfg.device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = msnake::launch_step(p, h->cfg.rules, 3, h->epb, s);
     if (e != hipSuccess) return fail(MSNAKE_E_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-    h->last_stream = s;
     h->env_steps += (int64_t)h->p.nenv * n_steps;
     return MSNAKE_OK;
 }
+
+// ---- canonical state import / export.  The device packs / unpacks (msnake_state_*_kernel); the host
+//      only sizes buffers and copies.  Blocking: every call starts with a device synchronise. ----
+namespace {
+
+struct BlobHeader {  // msnake_get_state_all / msnake_set_state_all
+    uint32_t magic, version;
+    int32_t num_envs, dim, n_snakes, n_fruits, rules, reserved;
+    uint64_t total_words;
+};
+constexpr uint32_t kBlobMagic = 0x5453534Du;  // "MSST"
+
+// need[i] (words) of envs [env0, env0 + count) -> host; offsets[count + 1] prefix sums
+int state_offsets(msnake_env* h, int env0, int count, std::vector<uint64_t>& offsets) {
+    if (int rc = ensure_scratch(h, (size_t)count * 4)) return rc;
+    HIP_TRY(msnake::launch_state_sizes(h->p, h->cfg.rules, env0, count, static_cast<uint32_t*>(h->d_scratch), nullptr));
+    std::vector<uint32_t> need((size_t)count);
+    HIP_TRY(hipMemcpy(need.data(), h->d_scratch, (size_t)count * 4, hipMemcpyDeviceToHost));
+    offsets.assign((size_t)count + 1, 0);
+    for (int i = 0; i < count; ++i) offsets[(size_t)i + 1] = offsets[(size_t)i] + need[(size_t)i];
+    return MSNAKE_OK;
+}
+
+// words of envs [env0, env0 + count) at `offsets` -> host buffer `out`
+int state_export(msnake_env* h, int env0, int count, const std::vector<uint64_t>& offsets, int32_t* out) {
+    const size_t off_bytes = ((size_t)count + 1) * 8, word_bytes = (size_t)offsets.back() * 4;
+    if (int rc = ensure_scratch(h, off_bytes + word_bytes)) return rc;
+    uint8_t* d = static_cast<uint8_t*>(h->d_scratch);
+    HIP_TRY(hipMemcpy(d, offsets.data(), off_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(msnake::launch_state_pack(h->p, h->cfg.rules, env0, count, reinterpret_cast<const uint64_t*>(d),
+                                      reinterpret_cast<int32_t*>(d + off_bytes), nullptr));
+    HIP_TRY(hipMemcpy(out, d + off_bytes, word_bytes, hipMemcpyDeviceToHost));
+    return MSNAKE_OK;
+}
+
+int state_import(msnake_env* h, int env0, int count, const uint64_t* offsets, const int32_t* words) {
+    const size_t off_bytes = ((size_t)count + 1) * 8, word_bytes = (size_t)offsets[count] * 4;
+    if (int rc = ensure_scratch(h, 16 + off_bytes + word_bytes)) return rc;
+    uint8_t* d = static_cast<uint8_t*>(h->d_scratch);
+    const uint32_t st0[4] = {0u, 0xFFFFFFFFu, 0u, 0u};
+    HIP_TRY(hipMemcpy(d, st0, 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d + 16, offsets, off_bytes, hipMemcpyHostToDevice));
+    if (word_bytes) HIP_TRY(hipMemcpy(d + 16 + off_bytes, words, word_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(msnake::launch_state_unpack(h->p, h->cfg.rules, env0, count, reinterpret_cast<const uint64_t*>(d + 16),
+                                        reinterpret_cast<const int32_t*>(d + 16 + off_bytes),
+                                        reinterpret_cast<uint32_t*>(d), nullptr));
+    uint32_t st[4];
+    HIP_TRY(hipMemcpy(st, d, 16, hipMemcpyDeviceToHost));
+    if (st[0] != 0)
+        return fail(MSNAKE_E_STATE, "%u env state(s) rejected; first: env %d: %s (the rejected envs were left untouched)", st[0],
+                    env0 + (int)st[1] - 1, state_reason(st[2]));
+    return MSNAKE_OK;
+}
+
+}  // namespace
 
 int msnake_get_state(msnake_handle h, int32_t env, int32_t* words, int32_t cap_words) {
     if (int rc = check(h)) return rc;
     if (env < 0 || env >= h->p.nenv) return fail(MSNAKE_E_ARG, "env %d out of range", env);
     DeviceGuard guard(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
-    const msnake::StepParams& p = h->p;
-    uint32_t hdr[MSNAKE_HDR_WORDS];
-    HIP_TRY(hipMemcpy(hdr, p.hdr + (size_t)env * MSNAKE_HDR_WORDS, sizeof(hdr), hipMemcpyDeviceToHost));
-    std::vector<uint16_t> ring((size_t)p.n_snakes * p.rest.cap);
-    HIP_TRY(hipMemcpy(ring.data(), p.ring + (size_t)env * p.n_snakes * p.rest.cap, ring.size() * 2, hipMemcpyDeviceToHost));
-    const bool adv = h->cfg.rules == MSNAKE_RULES_ADVERSARIAL;
-    const int nfr = adv ? (int)hdr[HDR_NLIST] : p.n_fruits;
-    std::vector<uint16_t> flist;
-    if (adv) {
-        flist.resize((size_t)p.fcap);
-        HIP_TRY(hipMemcpy(flist.data(), p.flist + (size_t)env * p.fcap, flist.size() * 2, hipMemcpyDeviceToHost));
-    }
-    int32_t need = 8 + 2 * nfr;
-    for (int s = 0; s < p.n_snakes; ++s) need += 6 + 2 * (int32_t)(hdr[SN_A(s)] >> 16);
+    std::vector<uint64_t> offsets;
+    if (int rc = state_offsets(h, env, 1, offsets)) return rc;
+    const int32_t need = (int32_t)offsets[1];
     if (!words || cap_words < need) return need;
-    int32_t k = 0;
-    words[k++] = (int32_t)hdr[HDR_T];
-    words[k++] = (int32_t)hdr[HDR_CTR_LO];
-    words[k++] = (int32_t)hdr[HDR_CTR_HI];
-    words[k++] = (int32_t)hdr[HDR_SPARE];
-    words[k++] = (int32_t)hdr[HDR_EP_LEN];
-    words[k++] = (int32_t)hdr[HDR_EP_RETURN];
-    words[k++] = nfr;
-    words[k++] = p.n_snakes;
-    for (int f = 0; f < nfr; ++f) {
-        const uint32_t c = adv ? (uint32_t)flist[(size_t)f] : (hdr[HDR_FRUIT0 + f] & 0xFFFFu);
-        words[k++] = (int32_t)(c >> 8) - 1;
-        words[k++] = (int32_t)(c & 255u) - 1;
-    }
-    for (int s = 0; s < p.n_snakes; ++s) {
-        const uint32_t w0 = hdr[SN_A(s)], w2 = hdr[SN_C(s)];
-        const int hp = (int)(w0 & 0xFFFFu), len = (int)(w0 >> 16), vel = (int)((w2 >> 16) & 7u);
-        words[k++] = len;
-        words[k++] = kVel0[vel];
-        words[k++] = kVel1[vel];
-        words[k++] = (int32_t)hdr[SN_B(s)];
-        const bool nw = h->cfg.rules == MSNAKE_RULES_NEW_WORLD;
-        words[k++] = nw ? (int32_t)((hdr[HDR_FLAGS] >> s) & 1u) : 1;
-        words[k++] = nw ? (int32_t)((hdr[HDR_FLAGS] >> (4 + s)) & 1u) : 0;
-        for (int i = 0; i < len; ++i) {
-            const uint32_t c = ring[(size_t)s * p.rest.cap + (size_t)((hp + i) % p.rest.cap)];
-            words[k++] = (int32_t)(c >> 8) - 1;
-            words[k++] = (int32_t)(c & 255u) - 1;
-        }
-    }
-    return k;
+    if (int rc = state_export(h, env, 1, offsets, words)) return rc;
+    return need;
 }
 
 int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t n) {
     if (int rc = check(h)) return rc;
     if (env < 0 || env >= h->p.nenv) return fail(MSNAKE_E_ARG, "env %d out of range", env);
-    const msnake::StepParams& p = h->p;
     if (!words || n < 8) return fail(MSNAKE_E_STATE, "state buffer too short");
-    if (words[7] != p.n_snakes) return fail(MSNAKE_E_STATE, "state has %d snakes, handle has %d", words[7], p.n_snakes);
-    const bool adv = h->cfg.rules == MSNAKE_RULES_ADVERSARIAL;
-    const int nfr = words[6];
-    if (!adv && nfr != p.n_fruits) return fail(MSNAKE_E_STATE, "state has %d fruits, handle has %d", nfr, p.n_fruits);
-    if (adv && (nfr < 0 || nfr > p.fcap)) return fail(MSNAKE_E_STATE, "fruit list of %d entries exceeds %d", nfr, p.fcap);
-    std::vector<uint16_t> flist(adv ? (size_t)p.fcap : 0, 0), fl0(adv ? 64 : 0, 0);
-    uint32_t hdr[MSNAKE_HDR_WORDS] = {0};
-    std::vector<uint16_t> ring((size_t)p.n_snakes * p.rest.cap, 0);
-    std::vector<uint16_t> body0((size_t)p.n_snakes * 64, 0);
-    auto cell = [&](int32_t c0, int32_t c1, uint32_t* out) -> bool {
-        if (c0 < -1 || c0 > p.dim || c1 < -1 || c1 > p.dim) return false;
-        *out = ((uint32_t)(c0 + 1) << 8) | (uint32_t)(c1 + 1);
-        return true;
-    };
-    int32_t k = 0;
-    hdr[HDR_T] = (uint32_t)words[k++];
-    hdr[HDR_CTR_LO] = (uint32_t)words[k++];
-    hdr[HDR_CTR_HI] = (uint32_t)words[k++];
-    hdr[HDR_SPARE] = (uint32_t)words[k++];
-    hdr[HDR_EP_LEN] = (uint32_t)words[k++];
-    hdr[HDR_EP_RETURN] = (uint32_t)words[k++];
-    k += 2;
-    if (n < k + 2 * nfr) return fail(MSNAKE_E_STATE, "state buffer truncated in fruits");
-    for (int f = 0; f < nfr; ++f, k += 2) {
-        uint32_t c;
-        if (!cell(words[k], words[k + 1], &c)) return fail(MSNAKE_E_STATE, "fruit %d outside [-1, dim]", f);
-        if (adv) {
-            flist[(size_t)f] = (uint16_t)c;
-            if (f < 64) fl0[(size_t)f] = (uint16_t)c;
-        } else {
-            hdr[HDR_FRUIT0 + f] = c;
-        }
-    }
-    if (adv) hdr[HDR_NLIST] = (uint32_t)nfr;
-    uint32_t flags = 0;
-    for (int s = 0; s < p.n_snakes; ++s) {
-        if (n < k + 6) return fail(MSNAKE_E_STATE, "state buffer truncated in snake %d", s);
-        const int len = words[k], v0 = words[k + 1], v1 = words[k + 2], grow = words[k + 3];
-        const int alive = words[k + 4], in_dead = words[k + 5];
-        k += 6;
-        if (len < 0 || len > p.rest.cap - 2 || n < k + 2 * len) return fail(MSNAKE_E_STATE, "snake %d: bad length %d", s, len);
-        uint32_t headc = 0;
-        for (int i = 0; i < len; ++i, k += 2) {
-            uint32_t c;
-            if (!cell(words[k], words[k + 1], &c)) return fail(MSNAKE_E_STATE, "snake %d piece %d outside [-1, dim]", s, i);
-            ring[(size_t)s * p.rest.cap + i] = (uint16_t)c;
-            if (i < 64) body0[(size_t)s * 64 + i] = (uint16_t)c;
-            if (i == 0) headc = c;
-        }
-        hdr[SN_A(s)] = 0u | ((uint32_t)len << 16);
-        hdr[SN_B(s)] = (uint32_t)grow;
-        hdr[SN_C(s)] = headc | ((uint32_t)vel_code(v0, v1) << 16);
-        if (alive) flags |= 1u << s;
-        if (in_dead) flags |= 16u << s;
-    }
-    hdr[HDR_FLAGS] = flags;
-    // every other word stays 0: in particular HDR_PC_VALID, so draws parked in the record for the old
-    // counter value are dropped.  The env's logging totals are not part of the canonical state: keep them.
+    if (words[7] != h->p.n_snakes) return fail(MSNAKE_E_STATE, "state has %d snakes, handle has %d", words[7], h->p.n_snakes);
     DeviceGuard guard(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&hdr[HDR_ACC_EPISODES], p.hdr + (size_t)env * MSNAKE_HDR_WORDS + HDR_ACC_EPISODES,
-                      4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(p.hdr + (size_t)env * MSNAKE_HDR_WORDS, hdr, sizeof(hdr), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(p.ring + (size_t)env * p.n_snakes * p.rest.cap, ring.data(), ring.size() * 2, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(p.body0 + (size_t)env * p.n_snakes * 64, body0.data(), body0.size() * 2, hipMemcpyHostToDevice));
-    if (adv) {
-        HIP_TRY(hipMemcpy(p.flist + (size_t)env * p.fcap, flist.data(), flist.size() * 2, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(p.fl0 + (size_t)env * 64, fl0.data(), fl0.size() * 2, hipMemcpyHostToDevice));
-    }
-    return MSNAKE_OK;
+    const uint64_t offsets[2] = {0, (uint64_t)n};
+    return state_import(h, env, 1, offsets, words);
+}
+
+int64_t msnake_get_state_all(msnake_handle h, void* buf, size_t cap_bytes) {
+    if (int rc = check(h)) return rc;
+    DeviceGuard guard(h->cfg.device);
+    HIP_TRY(hipDeviceSynchronize());
+    const int n = h->p.nenv;
+    std::vector<uint64_t> offsets;
+    if (int rc = state_offsets(h, 0, n, offsets)) return rc;
+    const size_t head = sizeof(BlobHeader) + ((size_t)n + 1) * 8;
+    const size_t need = head + (size_t)offsets.back() * 4;
+    if (!buf || cap_bytes < need) return (int64_t)need;
+    BlobHeader bh = {kBlobMagic, 1u, n, h->p.dim, h->p.n_snakes, h->p.n_fruits, h->cfg.rules, 0, offsets.back()};
+    uint8_t* out = static_cast<uint8_t*>(buf);
+    memcpy(out, &bh, sizeof(bh));
+    memcpy(out + sizeof(bh), offsets.data(), ((size_t)n + 1) * 8);
+    if (int rc = state_export(h, 0, n, offsets, reinterpret_cast<int32_t*>(out + head))) return rc;
+    return (int64_t)need;
+}
+
+int msnake_set_state_all(msnake_handle h, const void* buf, size_t bytes) {
+    if (int rc = check(h)) return rc;
+    if (!buf || bytes < sizeof(BlobHeader)) return fail(MSNAKE_E_STATE, "state blob too short");
+    BlobHeader bh;
+    memcpy(&bh, buf, sizeof(bh));
+    if (bh.magic != kBlobMagic || bh.version != 1u) return fail(MSNAKE_E_STATE, "not an msnake state blob (magic/version)");
+    const msnake::StepParams& p = h->p;
+    if (bh.num_envs != p.nenv || bh.dim != p.dim || bh.n_snakes != p.n_snakes || bh.rules != h->cfg.rules ||
+        (h->cfg.rules != MSNAKE_RULES_ADVERSARIAL && bh.n_fruits != p.n_fruits))
+        return fail(MSNAKE_E_STATE, "state blob is for %d envs, dim %d, %d snakes, %d fruits, rules %d; the handle differs",
+                    bh.num_envs, bh.dim, bh.n_snakes, bh.n_fruits, bh.rules);
+    const size_t n = (size_t)p.nenv, head = sizeof(BlobHeader) + (n + 1) * 8;
+    if (bytes < head) return fail(MSNAKE_E_STATE, "state blob truncated in its offset table");
+    std::vector<uint64_t> offsets(n + 1);
+    memcpy(offsets.data(), static_cast<const uint8_t*>(buf) + sizeof(bh), (n + 1) * 8);
+    if (offsets[0] != 0 || offsets[n] != bh.total_words || bytes < head + (size_t)bh.total_words * 4)
+        return fail(MSNAKE_E_STATE, "state blob truncated or its offset table is inconsistent");
+    for (size_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(MSNAKE_E_STATE, "state blob: offsets of env %zu decrease", i);
+    DeviceGuard guard(h->cfg.device);
+    HIP_TRY(hipDeviceSynchronize());
+    return state_import(h, 0, p.nenv, offsets.data(),
+                        reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(buf) + head));
 }
 
 int msnake_get_stats(msnake_handle h, msnake_stats* out, int32_t reset) {
     if (int rc = check(h)) return rc;
     if (!out) return fail(MSNAKE_E_ARG, "msnake_get_stats: out is NULL");
     DeviceGuard guard(h->cfg.device);
-    // the totals live in the env records; sum (and optionally clear) them behind the last step
-    HIP_TRY(hipMemsetAsync(h->d_stats, 0, 64, h->last_stream));
-    HIP_TRY(msnake::launch_stats(h->p.hdr, h->p.nenv, h->p.stats, reset ? 1 : 0, h->last_stream));
+    // the totals live in the env records; sum (and optionally clear) them once every step issued so
+    // far, on whatever stream, has finished (no stream handle is remembered between calls)
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemsetAsync(h->d_stats, 0, 64, nullptr));
+    HIP_TRY(msnake::launch_stats(h->p.hdr, h->p.nenv, h->p.stats, reset ? 1 : 0, nullptr));
     unsigned long long raw[8];
-    HIP_TRY(hipMemcpyAsync(raw, h->d_stats, sizeof(raw), hipMemcpyDeviceToHost, h->last_stream));
-    HIP_TRY(hipStreamSynchronize(h->last_stream));
+    HIP_TRY(hipMemcpy(raw, h->d_stats, sizeof(raw), hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
     out->episodes = (int64_t)raw[0];
     out->ep_len_sum = (int64_t)raw[1];
@@ -465,7 +484,7 @@ int msnake_get_stats(msnake_handle h, msnake_stats* out, int32_t reset) {
 
 const char* msnake_kernel_name(msnake_handle h) {
     if (check(h)) return "";
-    return msnake::step_kernel_name(h->cfg.rules, h->cfg.n_snakes, h->cfg.obs_scale);
+    return h->kname;  // owned by the handle: valid until msnake_destroy
 }
 
 int64_t msnake_algorithmic_bytes_per_env_step(msnake_handle h) {

@@ -1,21 +1,25 @@
 // msnake_kernels.hip -- the batched multi-snake environment step for gfx950 (MI355X, CDNA4).
 //
-// One 64-lane wavefront owns one environment for the whole step; a 512- or 256-thread workgroup carries
-// eight or four independent envs and never executes a workgroup barrier.  Design points:
-//   * ONE memory round trip before the wave can decide: the 256-byte env record (lane l <-> word
-//     l), the first 64 body cells of every snake (lane l <-> piece l) and the actions are all at
+// One 64-lane wavefront owns one environment for the whole step; a workgroup carries eight or four
+// independent envs and never executes a workgroup barrier.  Design points:
+//   * ONE memory round trip before the wave can decide: the env record (lane l <-> word l; 128 or 256
+//     bytes), the 64-slot body ring of every snake (lane l <-> slot l) and the actions are all at
 //     addresses that depend only on the env index, so they are issued together at kernel entry.
-//     Only bodies longer than 64 cells touch the full ring (dependent loads, rare).
+//     Only bodies longer than 64 cells touch their overflow ring (dependent loads, rare).
 //   * the env record stays in ONE VGPR for the whole kernel: scalar game logic reads fields with
-//     v_readlane and writes them back by lane select, so almost nothing is live in SGPRs;
-//   * body pieces are lane-distributed: a move is a one-lane shift of the chunk, collisions are
-//     compares + ballots (head-vs-piece matrix), fruit eating is a ballot over lane-resident fruits;
-//   * fruit respawn (slow path, once in the code): occupancy bytes in LDS -> per-chunk ballots
-//     parked in lanes -> k-th free cell by popcount / mbcnt; Philox4x32-10 on the scalar unit;
-//   * the observation is composed in LDS: a precomputed wall/background image (L2-resident,
-//     16 byte-shifted copies so that every LDS chunk equals a 16-byte ALIGNED global chunk) is
-//     copied with 16-byte LDS writes, fruit and body pixels are painted over it in reference
-//     order, and the image leaves as coalesced 16-byte global stores (1 KiB per wave instruction).
+//     v_readlane and writes them back by lane select, so almost nothing is live in SGPRs; the three
+//     per-snake columns of the record (lane s = snake s after a DPP row shift) let all snakes turn,
+//     move, eat and grow at once on the VALU;
+//   * body pieces are lane-distributed: a move overwrites ONE ring slot (the new head), collisions
+//     are compares + ballots (head-vs-piece matrix), fruit eating is a compare against the fruit lanes;
+//   * fruit respawn (slow path): one occupancy BIT per cell in LDS (ds_or) -> lane c owns the 64
+//     cells of chunk c as a register mask -> DPP prefix sum of the per-lane free counts -> k-th free
+//     cell; Philox4x32-10 on the VALU, lane l computing draw ctr + l (one evaluation = 64 draws);
+//   * the observation is composed in LDS: the wall/background image (L1/L2-resident) goes memory ->
+//     LDS directly (global_load_lds_dwordx4, no data VGPRs), fruit and body pixels are painted over
+//     it in reference order, and the image leaves as 16-byte-per-lane global stores (1 KiB contiguous
+//     per wave instruction);
+//   * write-back = what changed: the record, one 32-byte sector per moving snake, the outputs.
 // Integer / byte work bounded by the HBM writes of the observation tensor; no MFMA on purpose.
 //
 // Rules restated (reference paths under /root/reference/src/gym-snake/gym_snake/):
@@ -124,14 +128,14 @@ typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
 // K: integer pixel replication of the observation fused into the copy-out (the reference's WarpFrame,
 //    src/utils.py:15-31: cv2.resize to 84x84 with INTER_AREA, which for the exact integer up-scales
 //    used there -- 21->84 = x4, 12->84 = x7 -- is plain pixel replication)
-// The first 13 kernel-argument dwords (pointers + packed configuration) are preloaded into SGPRs
+// The first 14 kernel-argument dwords (pointers + packed configuration) are preloaded into SGPRs
 // by the dispatcher (-mllvm -amdgpu-kernarg-preload-count), so a wave can issue its state loads
 // without waiting for a scalar-memory round trip; the rarely used rest comes by value behind them.
 template <int RULES, int NS, int MODE, int K>
 __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     uint8_t* __restrict__ state, uint8_t* __restrict__ obs, const int32_t* __restrict__ actions,
     float* __restrict__ rew_out, uint8_t* __restrict__ done_out, const int32_t nenv, const uint32_t pk0,
-    const uint32_t pk1, const StepRest p) {
+    const uint32_t pk1, const uint32_t pk2, const StepRest p) {
     constexpr int VIEWS = RULES == MSNAKE_RULES_NEW_WORLD ? NS : 3;
     constexpr int C = 3 * VIEWS;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -150,10 +154,15 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     if (e >= nenv) return;
 
     // pk0 = dim | n_fruits<<6 | action_stride<<12 | auto_reset<<15 | max_steps<<16 ; pk1 = S | cap<<16
+    // pk2 = PK2_* flags
     const int dim = (int)(pk0 & 63u), nf = (int)((pk0 >> 6) & 63u), action_stride = (int)((pk0 >> 12) & 7u);
     const bool auto_reset = (pk0 >> 15) & 1u;
     const uint32_t max_steps = pk0 >> 16;
     const int S = (int)(pk1 & 0xFFFFu), cap = (int)(pk1 >> 16);
+    // inline fruits: record words FR0 .. FR0 + nf - 1 (lanes of hv)
+    constexpr int FR0 = RULES == MSNAKE_RULES_NEW_WORLD ? HDR_FRUIT0_N : HDR_FRUIT0_S;
+    // snake_env / adversarial can run on the first 128 bytes of the record (no parked Philox draws)
+    const bool short_rec = RULES != MSNAKE_RULES_NEW_WORLD && (pk2 & PK2_SHORT_REC);
     const int W = dim + 2, n2 = dim * dim;
     // LDS image: W rows of W*K pixels (already replicated horizontally when K > 1), padded to
     // whole 1 KiB wave-instructions
@@ -180,9 +189,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     uint16_t* body0_all = reinterpret_cast<uint16_t*>(state + (size_t)nenv * (MSNAKE_HDR_WORDS * 4));
     uint16_t* body0_g = body0_all + (size_t)e * NS * 64;
     const uint8_t* tmpl = reinterpret_cast<const uint8_t*>(body0_all + (size_t)nenv * NS * 64);
-    uint16_t* ring_g = reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl) + img_bytes) + (size_t)e * NS * cap;
-    uint32_t hv = hdr_g[lane];  // THE env record: lane l holds word l; lanes 32+f hold fruit f
-    uint32_t cr[NS];            // cr[s], lane l: piece l of snake s (valid while l < len)
+    uint16_t* ring_g = reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl) + img_bytes) + (size_t)e * NS * cap;  // overflow rings
+    uint32_t hv = 0;            // THE env record: lane l holds word l; lanes FR0+f hold fruit f
+    if (!short_rec || lane < MSNAKE_HDR_SHORT_WORDS) hv = hdr_g[lane];
+    uint32_t cr[NS];            // cr[s], lane l: slot l of snake s's body ring; piece i sits in slot (hp0 + i) & 63
 #pragma unroll
     for (int s = 0; s < NS; ++s) cr[s] = body0_g[s * 64 + lane];
     int actv = 0;
@@ -194,6 +204,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     uint16_t* fl0_g = nullptr;
     uint16_t* flist_g = nullptr;
     uint32_t fr = 0;
+    bool fr_dirty = false;      // fr changed in this launch (wave-uniform): chunk 0 of the list is written back
     if (RULES == MSNAKE_RULES_ADVERSARIAL) {
         uint16_t* fl0_all = reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl) + img_bytes) + (size_t)nenv * NS * cap;
         fl0_g = fl0_all + (size_t)e * 64;
@@ -246,18 +257,25 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         return (uint32_t)(((uint64_t)u * n) >> 32);
     };
 
-    // ---- per-piece visitor: f(i, cell) for every piece i of snake s (chunk 0 from registers,
-    //      pieces >= 64 from the ring) ----------------------------------------------------------
-    auto for_each_piece = [&](int s, uint32_t reg, int s_hp, int s_len, auto&& f) {
-        if (lane < s_len) f(lane, reg);
+    // ---- per-piece visitor: f(i, cell) for every piece i of snake s: the 64 most recent pieces from
+    //      the body ring in registers (slot (hp0 + i) & 63), pieces >= 64 from the overflow ring ----
+    //      wA / wC = the snake's SN_A / SN_C record words
+    auto for_each_piece = [&](int s, uint32_t reg, uint32_t wA, uint32_t wC, int s_len, auto&& f) {
+        const int i0 = (lane - (int)(wC >> SN_C_HP0_SHIFT)) & 63;
+        if (i0 < s_len) f(i0, reg);
         for (int base = 64; base < s_len; base += 64) {  // long bodies only
             const int i = base + lane;
             if (i < s_len) {
-                int idx = s_hp + i;
+                int idx = (int)(wA & 0xFFFFu) + i - 64;
                 idx = idx >= cap ? idx - cap : idx;
                 f(i, (uint32_t)__hip_atomic_load(&ring_g[(size_t)s * cap + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
         }
+    };
+    // the 32-byte sector of snake s's body ring that holds slot `slot` goes back to memory (whole
+    // sectors: nothing for the memory side to merge)
+    auto store_ring_sector = [&](int s, uint32_t reg, int slot) {
+        if ((lane >> 4) == (slot >> 4)) body0_g[s * 64 + lane] = (uint16_t)reg;
     };
 
     // [A] fruit-list visitor: f(i, cell) for every list entry i < nlist
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             }
             return n;
         }
-        return __builtin_popcountll(ballot(lane >= 32 && lane < 32 + nf && (hv & 0xFFFFu) == cell));
+        return __builtin_popcountll(ballot(lane >= FR0 && lane < FR0 + nf && (hv & 0xFFFFu) == cell));
     };
 
     // ---- fruit respawn: [S]:202-217 safe_choose_cell == [N]:235-247 get_safe_cell --------------
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 len -= (int)rdlane(bf_pop, j);
                 if (lane == 0) mark(0, rdlane(bf_nh, j));
             }
-            for_each_piece(j, cr[j], (int)(w0 & 0xFFFFu), len, mark);
+            for_each_piece(j, cr[j], w0, rdlane(hv, SN_C(j)), len, mark);
         }
         wave_sync();
         const int base = lane * 64;
@@ -351,18 +369,19 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             const uint32_t u = (uint32_t)__shfl((int)draws, (int)idx0 + lane);
             const uint32_t v = (uint32_t)(((uint64_t)u * (uint32_t)dim) >> 32) + 1u;  // padded coordinate
             const uint32_t cellv = (v << 8) | row_shl<1>(0u, v);                     // even lanes: (c0+1, c1+1)
-            hv = lane < NS ? (1u << 16) : hv;                    // SN_A: head_pos 0, len 1
+            hv = lane < NS ? (1u << 16) : hv;                    // SN_A: overflow empty, len 1
             hv = (lane >= 4 && lane < 4 + NS) ? 3u : hv;         // SN_B: grow_to 3
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const uint32_t hd = rdlane(cellv, 4 * s), fc = rdlane(cellv, 4 * s + 2);
-                HV_SET(SN_C(s), hd);  // head cell, velocity (0,0)
+                HV_SET(SN_C(s), hd);  // head cell, velocity (0,0), head in ring slot 0
                 cr[s] = hd;
-                if (lane == 0) ring_g[(size_t)s * cap] = (uint16_t)hd;
+                store_ring_sector(s, hd, 0);
                 if (RULES == MSNAKE_RULES_ADVERSARIAL) {  // fruits = [] then append ([A]:224-229)
                     if (lane == s) { fr = fc; flist_g[s] = (uint16_t)fc; }
+                    fr_dirty = true;
                 } else {
-                    HV_SET(HDR_FRUIT0 + s, fc);
+                    HV_SET(FR0 + s, fc);
                 }
             }
             const uint32_t nlo = ctr_lo + 4u * NS;
@@ -374,23 +393,23 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             for (int s = 0; s < NS; ++s) {
                 const uint32_t c0 = randint((uint32_t)dim), c1 = randint((uint32_t)dim);
                 const uint32_t hd = ((c0 + 1) << 8) | (c1 + 1);
-                HV_SET(SN_A(s), 1u << 16);   // head_pos 0, len 1
+                HV_SET(SN_A(s), 1u << 16);   // overflow empty, len 1
                 HV_SET(SN_B(s), 3u);         // grow_to 3
-                HV_SET(SN_C(s), hd);         // head cell, velocity (0,0)
+                HV_SET(SN_C(s), hd);         // head cell, velocity (0,0), head in ring slot 0
                 cr[s] = hd;
-                if (lane == 0) ring_g[(size_t)s * cap] = (uint16_t)hd;
+                store_ring_sector(s, hd, 0);
             }
         }
         if (RULES == MSNAKE_RULES_NEW_WORLD) {  // all snakes first, then n_fruits safe cells
             build_free();
             for (int f = 0; f < nf; ++f) {
                 const uint32_t c = safe_cell();
-                HV_SET(HDR_FRUIT0 + f, c);
+                HV_SET(FR0 + f, c);
             }
         }
         if (RULES == MSNAKE_RULES_ADVERSARIAL) HV_SET(HDR_NLIST, (uint32_t)NS);  // spare_fruits survives ([A]:14)
         HV_SET(HDR_T, 0u);
-        HV_SET(HDR_FLAGS, (1u << NS) - 1u);  // alive bits set, dead_snakes empty
+        HV_SET(HDR_FLAGS, (1u << NS) - 1u);  // alive bits set, dead_snakes empty, episode running
     };
 
     if (MODE == 1) {
@@ -440,7 +459,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         constexpr int NF_STATIC = RULES == MSNAKE_RULES_NEW_WORLD ? -1 : NS;  // [S]: one fruit per snake
         const uint32_t sA = hv, sB = row_shl<4>(0u, hv), sC = row_shl<8>(0u, hv);
         const int v_len = (int)(sA >> 16), v_hp = (int)(sA & 0xFFFFu), v_grow = (int)sB;
-        const int v_head = (int)(sC & 0xFFFFu), v_vel = (int)((sC >> 16) & 7u);
+        const int v_head = (int)(sC & 0xFFFFu), v_vel = (int)((sC >> 16) & 7u), v_hp0 = (int)((sC >> SN_C_HP0_SHIFT) & 63u);
         // turn unless it is a 180-degree reversal: [S]:108-115 == [N]:34-41 == [A]:106-113
         const int v_nvel = ((uint32_t)(actv - 1) < 4u && v_vel != ((actv + 1) & 3) + 1) ? actv : v_vel;
         // snake_env moves only with a velocity ([S]:119); new_world always inserts a head, even a
@@ -456,10 +475,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         } else if (NF_STATIC >= 0) {
 #pragma unroll
             for (int f = 0; f < (NF_STATIC >= 0 ? NF_STATIC : 0); ++f)
-                v_em |= ((uint32_t)v_nh == (rdlane(hv, HDR_FRUIT0 + f) & 0xFFFFu)) ? (1u << f) : 0u;
+                v_em |= ((uint32_t)v_nh == (rdlane(hv, FR0 + f) & 0xFFFFu)) ? (1u << f) : 0u;
         } else {
             for (int f = 0; f < nf; ++f)
-                v_em |= ((uint32_t)v_nh == (rdlane(hv, HDR_FRUIT0 + f) & 0xFFFFu)) ? (1u << f) : 0u;
+                v_em |= ((uint32_t)v_nh == (rdlane(hv, FR0 + f) & 0xFFFFu)) ? (1u << f) : 0u;
         }
         v_em = v_moves ? v_em : 0u;
         STAMP(1);
@@ -490,7 +509,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     const int f = __builtin_ffs((int)m) - 1;
                     m &= m - 1;
                     const uint32_t c = safe_cell();
-                    HV_SET(HDR_FRUIT0 + f, c);
+                    HV_SET(FR0 + f, c);
                     const uint32_t bit = (uint32_t)v_nh == c ? (1u << f) : 0u;
                     v_em = (v_moves && lane > s) ? ((v_em & ~(1u << f)) | bit) : v_em;
                 }
@@ -516,10 +535,14 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 HV_SET(HDR_ACC_ERRORS, rdlane(hv, HDR_ACC_ERRORS) + 1u);
                 nlen = nlen > cap - 1 ? cap - 1 : nlen;
             }
-            const int nhp = v_hp == 0 ? cap - 1 : v_hp - 1;
-            if (v_moves) ring_g[(size_t)lane * cap + nhp] = (uint16_t)v_nh;
-            const uint32_t nA = v_moves ? ((uint32_t)nhp | ((uint32_t)nlen << 16)) : sA;
-            const uint32_t nC = v_moves ? ((uint32_t)v_nh | ((uint32_t)v_nvel << 16)) : sC;
+            // the new head takes ring slot hp0 - 1, which held piece 63; if that piece stays part of the
+            // body (it becomes piece 64) it moves to the front of the overflow ring first
+            const int nhp0 = (v_hp0 - 1) & 63;
+            const bool v_evict = v_moves && v_len >= 64 && nlen >= 65;
+            const int nohp = v_evict ? (v_hp == 0 ? cap - 1 : v_hp - 1) : v_hp;
+            const uint32_t evmask = (uint32_t)ballot(v_evict);
+            const uint32_t nA = v_moves ? ((uint32_t)nohp | ((uint32_t)nlen << 16)) : sA;
+            const uint32_t nC = v_moves ? ((uint32_t)v_nh | ((uint32_t)v_nvel << 16) | ((uint32_t)nhp0 << SN_C_HP0_SHIFT)) : sC;
             hv = lane < NS ? nA : hv;
             if (RULES == MSNAKE_RULES_SNAKE_ENV) {
                 const uint32_t nB4 = row_shr<4>(hv, nB);
@@ -530,8 +553,11 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #pragma unroll
             for (int s = 0; s < NS; ++s)
                 if ((mvmask >> s) & 1ull) {
-                    const uint32_t sh = shift_up1(cr[s]);
-                    cr[s] = lane == 0 ? rdlane((uint32_t)v_nh, s) : sh;
+                    const int slot = (int)rdlane((uint32_t)nhp0, s);
+                    if (((evmask >> s) & 1u) && lane == slot)  // bodies of 64+ cells only
+                        ring_g[(size_t)s * cap + rdlane((uint32_t)nohp, s)] = (uint16_t)cr[s];
+                    cr[s] = lane == slot ? rdlane((uint32_t)v_nh, s) : cr[s];
+                    store_ring_sector(s, cr[s], slot);
                 }
         } else {
         // ---- 1b. sequential snake updates (order matters: a respawn sees earlier snakes moved,
@@ -548,8 +574,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             const int nh = head + cell_step(nvel);
             // fruits equal to the new head, as a bit mask over fruit indices (list rules: a count)
             const uint64_t em = RULES == MSNAKE_RULES_ADVERSARIAL ? 0ull :
-                ballot(lane >= 32 && lane < 32 + nf && (hv & 0xFFFFu) == (uint32_t)nh) >> 32;
+                ballot(lane >= FR0 && lane < FR0 + nf && (hv & 0xFFFFu) == (uint32_t)nh) >> FR0;
             const int neat = RULES == MSNAKE_RULES_ADVERSARIAL ? fruits_on((uint32_t)nh) : __builtin_popcountll(em);
+            const int len0 = len;
             int g = (int)rdlane(hv, SN_B(s));
             if (RULES == MSNAKE_RULES_NEW_WORLD) {
                 for (int f = 0; f < nf; ++f) {  // [N]:143-150: the pop test sits inside the fruit loop
@@ -562,17 +589,19 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             }
             len += 1;  // insert(0, head)
             if (len > cap - 1) { len = cap - 1; HV_SET(HDR_ACC_ERRORS, rdlane(hv, HDR_ACC_ERRORS) + 1u); }
-            int hp = (int)(w0 & 0xFFFFu);
-            hp = hp == 0 ? cap - 1 : hp - 1;
-            HV_SET(SN_A(s), (uint32_t)hp | ((uint32_t)len << 16));
+            int ohp = (int)(w0 & 0xFFFFu);
+            const int slot = ((int)(w2 >> SN_C_HP0_SHIFT) - 1) & 63;  // ring slot of the new head (held piece 63)
+            const bool evict = len0 >= 64 && len >= 65;              // piece 63 becomes piece 64: to the overflow ring
+            if (evict) ohp = ohp == 0 ? cap - 1 : ohp - 1;
+            HV_SET(SN_A(s), (uint32_t)ohp | ((uint32_t)len << 16));
             HV_SET(SN_B(s), (uint32_t)g);
-            HV_SET(SN_C(s), (uint32_t)nh | ((uint32_t)nvel << 16));
-            if (lane == 0) ring_g[(size_t)s * cap + hp] = (uint16_t)nh;
+            HV_SET(SN_C(s), (uint32_t)nh | ((uint32_t)nvel << 16) | ((uint32_t)slot << SN_C_HP0_SHIFT));
 #pragma unroll
             for (int j = 0; j < NS; ++j)
                 if (j == s) {
-                    const uint32_t sh = shift_up1(cr[j]);
-                    cr[j] = lane == 0 ? (uint32_t)nh : sh;
+                    if (evict && lane == slot) ring_g[(size_t)s * cap + ohp] = (uint16_t)cr[j];
+                    cr[j] = lane == slot ? (uint32_t)nh : cr[j];
+                    store_ring_sector(j, cr[j], slot);
                 }
             if (s == 0) reward = (float)neat;
             if (neat != 0) {  // respawn each eaten fruit, in index order
@@ -592,6 +621,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                             if (!built) { build_free(); built = true; }
                             const uint32_t nc = safe_cell();
                             if (base == 0 && lane == bit) fr = nc;
+                            fr_dirty = fr_dirty || base == 0;
                             if (lane == 0) flist_g[base + bit] = (uint16_t)nc;
                         }
                     }
@@ -604,7 +634,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                         const int f = __builtin_ffsll((long long)m) - 1;
                         m &= m - 1;
                         const uint32_t c = safe_cell();
-                        HV_SET(HDR_FRUIT0 + f, c);
+                        HV_SET(FR0 + f, c);
                     }
                 }
             }
@@ -615,22 +645,24 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         DBG_EXIT(2)
         // ---- 2. head-vs-piece matrix: some piece of snake j other than s's own head lies on
         //         s's head.  [S] only needs "any j" per s; [N] needs the full matrix -------------
-        uint32_t hd[NS], ln[NS], hp2[NS];
+        uint32_t hd[NS], ln[NS], hp2[NS], wc[NS];  // head cell, length, overflow head pos, SN_C word
         uint32_t maxlen = 0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const uint32_t w0 = rdlane(hv, SN_A(s));
-            hd[s] = rdlane(hv, SN_C(s)) & 0xFFFFu;
+            wc[s] = rdlane(hv, SN_C(s));
+            hd[s] = wc[s] & 0xFFFFu;
             ln[s] = w0 >> 16; hp2[s] = w0 & 0xFFFFu;
             maxlen = ln[s] > maxlen ? ln[s] : maxlen;
         }
         uint32_t hitl = 0;  // per-lane accumulation, bit (4*s + j)
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            const bool valid = (uint32_t)lane < ln[j];
+            const uint32_t pi = (uint32_t)(lane - (int)(wc[j] >> SN_C_HP0_SHIFT)) & 63u;  // piece index of this slot
+            const bool valid = pi < ln[j];
 #pragma unroll
             for (int s = 0; s < NS; ++s)
-                hitl |= (valid && cr[j] == hd[s] && !(j == s && lane == 0)) ? (1u << (4 * s + j)) : 0u;
+                hitl |= (valid && cr[j] == hd[s] && !(j == s && pi == 0)) ? (1u << (4 * s + j)) : 0u;
         }
         if (maxlen > 64) {  // bodies longer than one chunk: the rest comes from the ring
 #pragma unroll
@@ -638,7 +670,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 for (int base = 64; base < (int)ln[j]; base += 64) {
                     const int i = base + lane;
                     if (i < (int)ln[j]) {
-                        int idx = (int)hp2[j] + i;
+                        int idx = (int)hp2[j] + i - 64;
                         idx = idx >= cap ? idx - cap : idx;
                         const uint32_t cell = __hip_atomic_load(&ring_g[(size_t)j * cap + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
@@ -701,9 +733,11 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 for (int s = 0; s < NS; ++s) {
                     const int len_s = (int)ln[s];
                     if (((deadmask >> s) & 1u) && len_s > 0) {
-                        const uint32_t moved = (uint32_t)__shfl((int)cr[s], lane - nlist);
+                        // list entry nlist + i <- piece i: lane L of the first chunk takes ring slot hp0 + L - nlist
+                        const uint32_t moved = (uint32_t)__shfl((int)cr[s], ((int)(wc[s] >> SN_C_HP0_SHIFT) + lane - nlist) & 63);
                         if (lane >= nlist && lane < nlist + len_s) fr = moved;
-                        for_each_piece(s, cr[s], (int)hp2[s], len_s, [&](int i, uint32_t cell) {
+                        fr_dirty = true;
+                        for_each_piece(s, cr[s], hp2[s], wc[s], len_s, [&](int i, uint32_t cell) {
                             flist_g[nlist + i] = (uint16_t)cell;
                         });
                         nlist += len_s;
@@ -731,10 +765,17 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         if (done) {
             out_ret = ep_ret; out_len = ep_len;
             // logging totals stay in the env record (summed by msnake_get_stats): same-address
-            // atomics from every finishing env would serialise at ~12 ns each
-            if (lane == HDR_ACC_EPISODES) hv += 1u;
-            if (lane == HDR_ACC_LEN) hv += ep_len;
-            if (lane == HDR_ACC_RETURN) hv += (uint32_t)(int)ep_ret;
+            // atomics from every finishing env would serialise at ~12 ns each.  An episode counts once:
+            // without auto-reset a finished env keeps reporting done until the caller resets it.
+            const uint32_t fl = rdlane(hv, HDR_FLAGS);
+            if (!(fl & HDR_FLAG_FINISHED)) {
+                if (lane == HDR_ACC_EPISODES) hv += 1u;
+                if (lane == HDR_ACC_LEN) hv += ep_len;
+                const bool carry = ballot(lane == HDR_ACC_LEN && hv < ep_len) != 0;  // 64-bit length total
+                if (carry && lane == HDR_ACC_LEN_HI) hv += 1u;
+                if (lane == HDR_ACC_RETURN) hv += (uint32_t)(int)ep_ret;
+                HV_SET(HDR_FLAGS, fl | HDR_FLAG_FINISHED);
+            }
             if (auto_reset) {
                 ep_ret = 0.0f; ep_len = 0;
                 do_reset();
@@ -771,7 +812,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #pragma unroll
                     for (int v = 0; v < VIEWS; ++v) px[off + k * C + 3 * v] = 255;
             });
-        } else if (lane >= 32 && lane < 32 + nf) {
+        } else if (lane >= FR0 && lane < FR0 + nf) {
             const uint32_t cell = hv & 0xFFFFu;
             if (in_grid(cell, dim)) {
                 const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * (C * K);
@@ -788,7 +829,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         for (int j = 0; j < NS; ++j) {
             const uint32_t w0 = rdlane(hv, SN_A(j));
             if (RULES == MSNAKE_RULES_NEW_WORLD && !((flags >> j) & 1u)) continue;  // [N]:219
-            for_each_piece(j, cr[j], (int)(w0 & 0xFFFFu), (int)(w0 >> 16), [&](int i, uint32_t cell) {
+            for_each_piece(j, cr[j], w0, rdlane(hv, SN_C(j)), (int)(w0 >> 16), [&](int i, uint32_t cell) {
                 if (!in_grid(cell, dim)) return;
                 const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * (C * K);
                 const bool hd1 = i == 0;
@@ -813,7 +854,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             //         S%16 bytes go singly.
             uint8_t* obs_env = obs_t + (size_t)e * S;
             const int nfull = S >> 4;
-            if (MODE != 3 && p.stream_obs) {  // streaming (nt) stores, see msnake_capi.hip: obs_store_policy
+            if (MODE != 3 && (pk2 & PK2_STREAM_OBS)) {  // streaming (nt) stores, see msnake_capi.hip: obs_store_policy
                 for (int k = lane; k < nfull; k += 64)
                     __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(img)[k], reinterpret_cast<u32x4_unaligned*>(obs_env + 16 * k));
             } else {
@@ -830,7 +871,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             uint32_t* out = reinterpret_cast<uint32_t*>(obs_t + (size_t)e * S * (K * K));
             const uint32_t* src = reinterpret_cast<const uint32_t*>(img);
             const int rowdw = (W * K * C) >> 2;
-            if (MODE != 3 && p.stream_obs) {
+            if (MODE != 3 && (pk2 & PK2_STREAM_OBS)) {
                 for (int r = 0; r < W; ++r)
                     for (int q = lane; q < rowdw; q += 64) {
                         const uint32_t v = src[r * rowdw + q];
@@ -850,9 +891,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     STAMP(6);
     }  // step loop
 
-    // ---- 5. state write-back (once per launch) ---------------------------
+    // ---- 5. state write-back (once per launch): the record; the body rings went out slot by slot --
     if (MODE != 2) {
-        if (PCACHE && refilled) {
+        if (PCACHE && refilled && !short_rec) {
             // Philox ran in this launch: its unused draws go into the record for the launches to come
             const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO);
             const uint32_t off = ctr_lo - draw_base;
@@ -865,10 +906,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 HV_SET(HDR_PC_VALID, 0u);
             }
         }
-        hdr_g[lane] = hv;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) body0_g[s * 64 + lane] = (uint16_t)cr[s];
-        if (RULES == MSNAKE_RULES_ADVERSARIAL) fl0_g[lane] = (uint16_t)fr;
+        if (!short_rec || lane < MSNAKE_HDR_SHORT_WORDS) hdr_g[lane] = hv;
+        if (RULES == MSNAKE_RULES_ADVERSARIAL && fr_dirty) fl0_g[lane] = (uint16_t)fr;
     }
 
 }
@@ -879,8 +918,9 @@ __global__ __launch_bounds__(256) void msnake_stats_kernel(uint32_t* __restrict_
     long long ep = 0, ln = 0, rt = 0, er = 0;
     for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < nenv; e += (int)(gridDim.x * blockDim.x)) {
         uint32_t* h = hdr + (size_t)e * MSNAKE_HDR_WORDS;
-        ep += h[HDR_ACC_EPISODES]; ln += h[HDR_ACC_LEN]; rt += (int)h[HDR_ACC_RETURN]; er += h[HDR_ACC_ERRORS];
-        if (clear) h[HDR_ACC_EPISODES] = h[HDR_ACC_LEN] = h[HDR_ACC_RETURN] = h[HDR_ACC_ERRORS] = 0u;
+        ep += h[HDR_ACC_EPISODES]; ln += (long long)(((unsigned long long)h[HDR_ACC_LEN_HI] << 32) | h[HDR_ACC_LEN]);
+        rt += (int)h[HDR_ACC_RETURN]; er += h[HDR_ACC_ERRORS];
+        if (clear) h[HDR_ACC_EPISODES] = h[HDR_ACC_LEN] = h[HDR_ACC_LEN_HI] = h[HDR_ACC_RETURN] = h[HDR_ACC_ERRORS] = 0u;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -901,6 +941,195 @@ hipError_t launch_stats(uint32_t* hdr, int nenv, unsigned long long* stats, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// canonical state export / import (msnake_get_state[_all] / msnake_set_state[_all]; checkpoint and
+// test path, off the step path).  Word layout per env: include/msnake.h.  One wave per env.
+// ------------------------------------------------------------------------------------------------
+struct StateView {
+    uint32_t* hdr; uint16_t* body0; uint16_t* ovf; uint16_t* fl0; uint16_t* flist;
+    int32_t nenv, dim, ns, nf, cap, fcap, rules;
+};
+
+static StateView state_view(const StepParams& p, int rules) {
+    return StateView{p.hdr, p.body0, p.ring, p.fl0, p.flist, p.nenv, p.dim, p.n_snakes, p.n_fruits, p.rest.cap, p.fcap, rules};
+}
+
+__device__ __forceinline__ int state_fruit_count(const StateView& v, const uint32_t* h) {
+    return v.rules == MSNAKE_RULES_ADVERSARIAL ? (int)h[HDR_NLIST] : v.nf;
+}
+
+__global__ __launch_bounds__(256) void msnake_state_sizes_kernel(StateView v, int env0, int count, uint32_t* __restrict__ need) {
+    const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (w >= count) return;
+    const uint32_t* h = v.hdr + (size_t)(env0 + w) * MSNAKE_HDR_WORDS;
+    uint32_t n = 8u + 2u * (uint32_t)state_fruit_count(v, h);
+    for (int s = 0; s < v.ns; ++s) n += 6u + 2u * (h[SN_A(s)] >> 16);
+    need[w] = n;
+}
+
+__global__ __launch_bounds__(256) void msnake_state_pack_kernel(StateView v, int env0, int count,
+                                                                const uint64_t* __restrict__ offsets, int32_t* __restrict__ words) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const int w = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (w >= count) return;
+    const int e = env0 + w;
+    const uint32_t* h = v.hdr + (size_t)e * MSNAKE_HDR_WORDS;
+    int32_t* out = words + offsets[w];
+    const bool adv = v.rules == MSNAKE_RULES_ADVERSARIAL, nw = v.rules == MSNAKE_RULES_NEW_WORLD;
+    const int nfr = state_fruit_count(v, h), fr0 = nw ? HDR_FRUIT0_N : HDR_FRUIT0_S;
+    if (lane == 0) {
+        out[0] = (int32_t)h[HDR_T]; out[1] = (int32_t)h[HDR_CTR_LO]; out[2] = (int32_t)h[HDR_CTR_HI];
+        out[3] = (int32_t)h[HDR_SPARE]; out[4] = (int32_t)h[HDR_EP_LEN]; out[5] = (int32_t)h[HDR_EP_RETURN];
+        out[6] = nfr; out[7] = v.ns;
+    }
+    size_t k = 8;
+    for (int f = lane; f < nfr; f += 64) {
+        const uint32_t c = adv ? (uint32_t)v.flist[(size_t)e * v.fcap + f] : (h[fr0 + f] & 0xFFFFu);
+        out[k + 2 * f] = (int32_t)(c >> 8) - 1;
+        out[k + 2 * f + 1] = (int32_t)(c & 255u) - 1;
+    }
+    k += 2 * (size_t)nfr;
+    for (int s = 0; s < v.ns; ++s) {
+        const uint32_t wA = h[SN_A(s)], wC = h[SN_C(s)];
+        const int len = (int)(wA >> 16), ohp = (int)(wA & 0xFFFFu), hp0 = (int)((wC >> SN_C_HP0_SHIFT) & 63u);
+        const int vel = (int)((wC >> 16) & 7u);
+        if (lane == 0) {
+            out[k] = len;
+            out[k + 1] = vel == 1 ? 1 : vel == 3 ? -1 : 0;
+            out[k + 2] = vel == 2 ? 1 : vel == 4 ? -1 : 0;
+            out[k + 3] = (int32_t)h[SN_B(s)];
+            out[k + 4] = nw ? (int32_t)((h[HDR_FLAGS] >> s) & 1u) : 1;
+            out[k + 5] = nw ? (int32_t)((h[HDR_FLAGS] >> (4 + s)) & 1u) : 0;
+        }
+        for (int i = lane; i < len; i += 64) {
+            uint32_t c;
+            if (i < 64) {
+                c = v.body0[((size_t)e * v.ns + s) * 64 + ((hp0 + i) & 63)];
+            } else {
+                int idx = ohp + i - 64;
+                idx = idx >= v.cap ? idx - v.cap : idx;
+                c = v.ovf[((size_t)e * v.ns + s) * v.cap + idx];
+            }
+            out[k + 6 + 2 * (size_t)i] = (int32_t)(c >> 8) - 1;
+            out[k + 6 + 2 * (size_t)i + 1] = (int32_t)(c & 255u) - 1;
+        }
+        k += 6 + 2 * (size_t)len;
+    }
+}
+
+// status[0]: number of rejected envs, status[1]: lowest rejected local index + 1 (atomicMin on ~0u), status[2]: its MSNAKE_ST_* reason
+#define MSNAKE_ST_SHORT 1      // buffer too short / truncated
+#define MSNAKE_ST_SNAKES 2     // snake count differs from the handle
+#define MSNAKE_ST_FRUITS 3     // fruit count differs from the handle / exceeds the list capacity
+#define MSNAKE_ST_CELL 4       // a cell outside [-1, dim]
+#define MSNAKE_ST_LEN 5        // a body length outside [0, cap - 2]
+__global__ __launch_bounds__(256) void msnake_state_unpack_kernel(StateView v, int env0, int count,
+                                                                  const uint64_t* __restrict__ offsets,
+                                                                  const int32_t* __restrict__ words, uint32_t* __restrict__ status) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const int w = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (w >= count) return;
+    const int e = env0 + w;
+    const int32_t* in = words + offsets[w];
+    const long long n = (long long)(offsets[w + 1] - offsets[w]);
+    const bool adv = v.rules == MSNAKE_RULES_ADVERSARIAL, nw = v.rules == MSNAKE_RULES_NEW_WORLD;
+    auto cell_ok = [&](int c0, int c1) { return c0 >= -1 && c0 <= v.dim && c1 >= -1 && c1 <= v.dim; };
+    // ---- pass 1: validate everything before anything is written
+    int bad = 0;
+    int nfr = 0;
+    if (n < 8) bad = MSNAKE_ST_SHORT;
+    else if (in[7] != v.ns) bad = MSNAKE_ST_SNAKES;
+    else {
+        nfr = in[6];
+        if (adv ? (nfr < 0 || nfr > v.fcap) : nfr != v.nf) bad = MSNAKE_ST_FRUITS;
+        else if (n < 8 + 2LL * nfr) bad = MSNAKE_ST_SHORT;
+    }
+    long long k = 8;
+    if (!bad) {
+        bool okc = true;
+        for (int f = lane; f < nfr; f += 64) okc = okc && cell_ok(in[k + 2 * f], in[k + 2 * f + 1]);
+        if (__builtin_amdgcn_ballot_w64(!okc) != 0) bad = MSNAKE_ST_CELL;
+        k += 2LL * nfr;
+    }
+    for (int s = 0; s < v.ns && !bad; ++s) {
+        if (n < k + 6) { bad = MSNAKE_ST_SHORT; break; }
+        const int len = in[k];
+        if (len < 0 || len > v.cap - 2) { bad = MSNAKE_ST_LEN; break; }
+        if (n < k + 6 + 2LL * len) { bad = MSNAKE_ST_SHORT; break; }
+        bool okc = true;
+        for (int i = lane; i < len; i += 64) okc = okc && cell_ok(in[k + 6 + 2LL * i], in[k + 6 + 2LL * i + 1]);
+        if (__builtin_amdgcn_ballot_w64(!okc) != 0) { bad = MSNAKE_ST_CELL; break; }
+        k += 6 + 2LL * len;
+    }
+    if (bad) {
+        if (lane == 0) {
+            atomicAdd(&status[0], 1u);
+            if (atomicMin(&status[1], (uint32_t)w + 1u) > (uint32_t)w + 1u) status[2] = (uint32_t)bad;
+        }
+        return;
+    }
+    // ---- pass 2: the record (lane l builds word l; logging totals are not part of the canonical
+    //      state and stay; every other word, the parked Philox draws included, is cleared)
+    uint32_t* h = v.hdr + (size_t)e * MSNAKE_HDR_WORDS;
+    uint32_t hv = (lane >= HDR_ACC_EPISODES && lane <= HDR_ACC_LEN_HI) ? h[lane] : 0u;
+    HV_SET(HDR_T, in[0]); HV_SET(HDR_CTR_LO, in[1]); HV_SET(HDR_CTR_HI, in[2]); HV_SET(HDR_SPARE, in[3]);
+    HV_SET(HDR_EP_LEN, in[4]); HV_SET(HDR_EP_RETURN, in[5]);
+    if (adv) HV_SET(HDR_NLIST, nfr);
+    k = 8;
+    const int fr0 = nw ? HDR_FRUIT0_N : HDR_FRUIT0_S;
+    for (int f = lane; f < nfr; f += 64) {
+        const uint32_t c = ((uint32_t)(in[k + 2 * f] + 1) << 8) | (uint32_t)(in[k + 2 * f + 1] + 1);
+        if (adv) {
+            v.flist[(size_t)e * v.fcap + f] = (uint16_t)c;
+            if (f < 64) v.fl0[(size_t)e * 64 + f] = (uint16_t)c;
+        }
+    }
+    if (!adv)
+        for (int f = 0; f < nfr; ++f)
+            HV_SET(fr0 + f, ((uint32_t)(in[k + 2 * f] + 1) << 8) | (uint32_t)(in[k + 2 * f + 1] + 1));
+    k += 2LL * nfr;
+    uint32_t flags = 0;
+    for (int s = 0; s < v.ns; ++s) {
+        const int len = in[k], v0 = in[k + 1], v1 = in[k + 2];
+        const int vel = (v0 == 1 && v1 == 0) ? 1 : (v0 == 0 && v1 == 1) ? 2 : (v0 == -1 && v1 == 0) ? 3 : (v0 == 0 && v1 == -1) ? 4 : 0;
+        if (in[k + 4]) flags |= 1u << s;
+        if (in[k + 5]) flags |= 16u << s;
+        uint32_t headc = 0;
+        if (len > 0) headc = ((uint32_t)(in[k + 6] + 1) << 8) | (uint32_t)(in[k + 7] + 1);
+        for (int i = lane; i < len; i += 64) {
+            const uint32_t c = ((uint32_t)(in[k + 6 + 2LL * i] + 1) << 8) | (uint32_t)(in[k + 6 + 2LL * i + 1] + 1);
+            if (i < 64) v.body0[((size_t)e * v.ns + s) * 64 + i] = (uint16_t)c;          // head in slot 0
+            else v.ovf[((size_t)e * v.ns + s) * v.cap + (i - 64)] = (uint16_t)c;         // overflow from position 0
+        }
+        HV_SET(SN_A(s), (uint32_t)len << 16);
+        HV_SET(SN_B(s), in[k + 3]);
+        HV_SET(SN_C(s), headc | ((uint32_t)vel << 16));
+        k += 6 + 2LL * len;
+    }
+    HV_SET(HDR_FLAGS, flags);
+    h[lane] = hv;
+}
+
+hipError_t launch_state_sizes(const StepParams& p, int rules, int env0, int count, uint32_t* need_words, hipStream_t stream) {
+    hipLaunchKernelGGL(msnake_state_sizes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
+                       state_view(p, rules), env0, count, need_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_state_pack(const StepParams& p, int rules, int env0, int count, const uint64_t* offsets, int32_t* words,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(msnake_state_pack_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, stream,
+                       state_view(p, rules), env0, count, offsets, words);
+    return hipGetLastError();
+}
+
+hipError_t launch_state_unpack(const StepParams& p, int rules, int env0, int count, const uint64_t* offsets,
+                               const int32_t* words, uint32_t* status, hipStream_t stream) {
+    hipLaunchKernelGGL(msnake_state_unpack_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, stream,
+                       state_view(p, rules), env0, count, offsets, words, status);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch glue (called from the C-ABI in msnake_capi.hip)
 // ------------------------------------------------------------------------------------------------
 template <int RULES, int NS, int K>
@@ -910,10 +1139,11 @@ static hipError_t launch_k(const StepParams& p, int mode, int epb, hipStream_t s
     const uint32_t pk0 = (uint32_t)p.dim | ((uint32_t)p.n_fruits << 6) | ((uint32_t)p.action_stride << 12) |
                          ((uint32_t)(p.auto_reset ? 1 : 0) << 15) | ((uint32_t)p.rest.max_steps << 16);
     const uint32_t pk1 = (uint32_t)p.S | ((uint32_t)p.rest.cap << 16);
+    const uint32_t pk2 = (p.short_rec ? PK2_SHORT_REC : 0u) | (p.rest.stream_obs ? PK2_STREAM_OBS : 0u);
     const size_t lds = (size_t)p.lds_per_wave * (size_t)epb;
 #define MSNAKE_LAUNCH(M)                                                                                       \
     hipLaunchKernelGGL((msnake_step_kernel<RULES, NS, M, K>), grid, block, lds, stream, p.state, p.obs, p.actions, \
-                       p.rest.rew, p.rest.done, p.nenv, pk0, pk1, p.rest)
+                       p.rest.rew, p.rest.done, p.nenv, pk0, pk1, pk2, p.rest)
     switch (mode) {
         case 0: MSNAKE_LAUNCH(0); break;
         case 1: MSNAKE_LAUNCH(1); break;
@@ -957,10 +1187,8 @@ hipError_t launch_step(const StepParams& p, int rules, int mode, int epb, hipStr
     }
 }
 
-static char g_kname[64];
-const char* step_kernel_name(int rules, int n_snakes, int obs_scale) {
-    snprintf(g_kname, sizeof(g_kname), "msnake_step_kernel<%d, %d, 0, %d>", rules, n_snakes, obs_scale);
-    return g_kname;
+void step_kernel_name(int rules, int n_snakes, int obs_scale, char* out, size_t n) {
+    snprintf(out, n, "msnake_step_kernel<%d, %d, 0, %d>", rules, n_snakes, obs_scale);
 }
 
 }  // namespace msnake

@@ -250,6 +250,17 @@ class MultiSnakeVecEnv:
         w = np.ascontiguousarray(words, dtype=np.int32)
         _capi.check(self._L.msnake_set_state(self._h, env, w.ctypes.data, len(w)), "msnake_set_state")
 
+    def get_state_all(self):
+        """Canonical state of every env as one bytes-like blob (numpy uint8; layout: include/msnake.h)."""
+        n = _capi.check(self._L.msnake_get_state_all(self._h, None, 0), "msnake_get_state_all")
+        buf = np.zeros(n, np.uint8)
+        _capi.check(self._L.msnake_get_state_all(self._h, buf.ctypes.data, n), "msnake_get_state_all")
+        return buf
+
+    def set_state_all(self, blob):
+        b = np.ascontiguousarray(np.frombuffer(blob, np.uint8) if not isinstance(blob, np.ndarray) else blob, dtype=np.uint8)
+        _capi.check(self._L.msnake_set_state_all(self._h, b.ctypes.data, b.nbytes), "msnake_set_state_all")
+
     def stats(self, reset=False):
         st = _capi.MsnakeStats()
         _capi.check(self._L.msnake_get_stats(self._h, ctypes.byref(st), int(reset)), "msnake_get_stats")

@@ -597,3 +597,151 @@ def test_step_is_hip_graph_capturable():
         o, r, d, i = b.step_device(tape[t])
         assert torch.equal(a._obs, o) and torch.equal(a._rew, r) and torch.equal(a._done, d) and torch.equal(a._info, i), t
     a.close(); b.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 2: large batches (BASELINE configs[3] sizes and beyond), bulk state I/O, configs[4] at full size
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("num_envs,base,steps", [(16384, 0, 40), (32768, 7 * 4096, 48), (65536, 0, 40)])
+def test_large_batches_byte_for_byte(num_envs, base, steps):
+    """> 8 192 envs switch to 4 envs per workgroup, the short (128-byte) record, many 64-workgroup
+    groups of the XCD-aware env mapping, plain observation stores (62 / 124 MiB per step) and, at
+    65 536 envs (248 MiB), streaming ones again.  32 768 envs = BASELINE configs[3]; its run owns the
+    global ids of rank 7 of 8 (env_id_base 7 x 4 096).  Every observation byte is compared."""
+    assert _run_vs_oracle(num_envs, 19, 3, 3, "snake_env", steps, seed=3, env_id_base=base) > num_envs
+
+
+@pytest.mark.parametrize("rules,ns,nf", [("new_world", 3, 3), ("adversarial", 2, 2)])
+def test_large_batches_other_rule_sets(rules, ns, nf):
+    _run_vs_oracle(20000, 10, ns, nf, rules, 30, seed=14)
+
+
+@pytest.mark.parametrize("short_rec", ["0", "1"])
+def test_record_policy_is_invisible(short_rec, monkeypatch):
+    """snake_env / adversarial steps run on the full 256-byte record (Philox draws parked in its upper
+    half) or on its first 128 bytes; the library picks by batch size, MSNAKE_SHORT_REC forces it."""
+    monkeypatch.setenv("MSNAKE_SHORT_REC", short_rec)
+    assert _run_vs_oracle(3000, 19, 3, 3, "snake_env", 120, seed=15) > 1000
+    _run_vs_oracle(1500, 10, 3, 3, "adversarial", 150, seed=16, greedy=0.5)
+    _run_vs_oracle(700, 6, 3, 3, "snake_env", 120, seed=17, greedy=0.3)
+
+
+def test_config4_selfplay_at_full_size():
+    """BASELINE configs[4]: 4 096 envs x 2 snakes x 19x19 driving self-play PPO rollouts end to end
+    (PyTorch policy on the same GPU, HIP env through step_device): two updates of 16-step rollouts,
+    the env's own episode totals cross-checked against what the rollouts reported; and the same env
+    shape against the oracle.  Reference: ppo_multi_agent.py:170-216 (Runner.run), :231-404 (learn)."""
+    from msnake import selfplay
+    n, nsteps = 4096, 16
+    env = _mk(num_envs=n, dim=19, n_snakes=2, rules="snake_env", seed=31)
+    model, hist = selfplay.learn(env, nsteps=nsteps, total_timesteps=n * nsteps * 2, nminibatches=8, noptepochs=1, log_fn=None)
+    assert len(hist) == 2 and hist[-1]["total_timesteps"] == n * nsteps * 2
+    assert np.isfinite(hist[-1]["policy_loss"]) and np.isfinite(hist[-1]["value_loss"])
+    st = env.stats()
+    assert st["env_steps"] == n * nsteps * 2 and st["errors"] == 0 and st["episodes"] > 1000
+    env.close()
+    env = _mk(num_envs=n, dim=19, n_snakes=2, rules="snake_env", seed=32)
+    pol = selfplay.CnnPolicy((21, 21, 3)).to(env.device)
+    runner = selfplay.Runner(env, pol, [pol], nsteps, 0.99, 0.95)
+    env.stats(reset=True)
+    epinfos = runner.run()[-1]
+    st = env.stats()
+    assert st["episodes"] == len(epinfos) > 500
+    assert st["ep_len_sum"] == sum(e["l"] for e in epinfos) and st["ep_return_sum"] == round(sum(e["r"] for e in epinfos))
+    env.close()
+    assert _run_vs_oracle(4096, 19, 2, 2, "snake_env", 150, seed=33) > 1000
+
+
+@pytest.mark.parametrize("rules,dim,ns,nf", [("snake_env", 19, 3, 3), ("new_world", 10, 3, 5), ("adversarial", 10, 3, 3)])
+def test_bulk_state_round_trip(rules, dim, ns, nf):
+    """msnake_get_state_all / msnake_set_state_all: one packing kernel + one copy for all 4 096 envs;
+    the blob must hold exactly what 4 096 msnake_get_state calls return, restore the handle it came
+    from, and seed a second handle that then continues bit for bit."""
+    n = 4096
+    a = _mk(num_envs=n, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=51)
+    a.reset()
+    rs = np.random.default_rng(8)
+    for _ in range(70):
+        a.step(np.where(rs.random((n, ns)) < 0.6, 0, rs.integers(0, 5, (n, ns))).astype(np.int32))
+    blob = a.get_state_all()
+    head = np.frombuffer(blob[:40].tobytes(), np.int32)
+    assert bytes(blob[:4]) == b"MSST" and head[2] == n and head[3] == dim and head[4] == ns
+    offs = np.frombuffer(blob[40:40 + 8 * (n + 1)].tobytes(), np.uint64)
+    words = np.frombuffer(blob[40 + 8 * (n + 1):].tobytes(), np.int32)
+    assert offs[0] == 0 and offs[-1] == len(words)
+    for e in range(0, n, 29):
+        assert np.array_equal(words[int(offs[e]):int(offs[e + 1])], a.get_state_words(e)), e
+    ref_obs = a.render().copy()
+    snap = [a.get_state_words(e).copy() for e in range(0, n, 101)]
+    acts = rs.integers(0, 5, (25, n, ns)).astype(np.int32)
+    cont = [a.step(acts[t]) for t in range(25)]           # a moves on ...
+    cont = [(o.copy(), r.copy(), d.copy()) for o, r, d, _ in cont]
+    b = _mk(num_envs=n, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=51)
+    b.reset()
+    b.set_state_all(blob)                                  # ... b starts from the checkpoint
+    assert np.array_equal(b.render(), ref_obs)
+    for t in range(25):
+        o, r, d, _ = b.step(acts[t])
+        assert np.array_equal(o, cont[t][0]) and np.array_equal(r, cont[t][1]) and np.array_equal(d, cont[t][2]), t
+    a.set_state_all(blob)                                  # and a can be rolled back
+    assert np.array_equal(a.render(), ref_obs)
+    for k, e in enumerate(range(0, n, 101)):
+        assert np.array_equal(a.get_state_words(e), snap[k]), e
+    # malformed blobs are refused and say why
+    bad = blob.copy(); bad[0] ^= 0xFF
+    with pytest.raises(RuntimeError, match="blob"):
+        a.set_state_all(bad)
+    with pytest.raises(RuntimeError, match="truncated"):
+        a.set_state_all(blob[:len(blob) - 4])
+    c = _mk(num_envs=n // 2, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=51)
+    with pytest.raises(RuntimeError, match="handle differs"):
+        c.set_state_all(blob)
+    # a cell off the board in one env's words: that env is named and left untouched
+    w = words.copy()
+    victim = None
+    for e in range(n):
+        pos = int(offs[e]) + 8 + 2 * int(w[int(offs[e]) + 6])   # snake 0's block: len, v0, v1, grow, alive, in_dead, cells
+        if w[pos] > 0:
+            w[pos + 6] = dim + 7
+            victim = e
+            break
+    assert victim is not None
+    bad = np.concatenate([blob[:40 + 8 * (n + 1)], np.frombuffer(w.tobytes(), np.uint8)])
+    before = a.get_state_words(victim).copy()
+    with pytest.raises(RuntimeError, match=f"env {victim}:"):
+        a.set_state_all(bad)
+    assert np.array_equal(a.get_state_words(victim), before)
+    for env in (a, b, c):
+        env.close()
+
+
+def test_episode_totals_without_auto_reset_count_once():
+    """auto_reset = 0: a finished env keeps returning done until the caller resets it, but the
+    msnake_get_stats totals count that episode once."""
+    n = 64
+    env = _mk(num_envs=n, dim=6, n_snakes=2, rules="snake_env", seed=61, auto_reset=False, max_steps=12)
+    env.reset()
+    rs = np.random.default_rng(2)
+    first_done = np.zeros(n, bool)
+    for _ in range(30):
+        _, _, done, _ = env.step(rs.integers(0, 5, (n, 2)).astype(np.int32))
+        first_done |= done
+    assert first_done.all()  # the 12-step cap has ended every episode, many steps ago
+    assert env.stats()["episodes"] == n
+    env.reset()
+    for _ in range(30):
+        env.step(rs.integers(0, 5, (n, 2)).astype(np.int32))
+    assert env.stats()["episodes"] == 2 * n
+    env.close()
+
+
+def test_obs_alignment_is_checked_for_the_fused_upscale():
+    import torch
+    env = _mk(num_envs=8, dim=10, n_snakes=1, rules="snake_env", seed=1, obs_scale=7)
+    H, W, C = env.obs_shape
+    buf = torch.empty(8 * H * W * C + 8, dtype=torch.uint8, device=env.device)
+    acts = torch.zeros((8, 1), dtype=torch.int32, device=env.device)
+    rc = env._L.msnake_step(env._h, acts.data_ptr(), 1, buf.data_ptr() + 1, env._rew.data_ptr(), env._done.data_ptr(),
+                            env._info.data_ptr(), env._stream())
+    assert rc == -4 and b"aligned" in env._L.msnake_last_error()
+    env.close()

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     lib = msnake._capi.load()
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.msnake_abi_version() == 1
+    assert lib.msnake_abi_version() == 2
 
 
 def test_struct_layouts_match_header():

@@ -91,3 +91,27 @@ def test_multithreaded_step_matches_single():
         rb = [x.copy() for x in b.step(act, threads=4)]
         for x, y in zip(ra, rb):
             assert np.array_equal(x, y)
+
+
+def test_philox_streams_equal_rocrand_engine(tmp_path):
+    """the (seed, subsequence = global env id, offset = draw index) convention of
+    include/msnake.h IS rocRAND's: the first 16 outputs of rocrand_device::philox4x32_10_engine,
+    compiled for the host from the installed rocRAND header (oracle/rocrand_kat.cpp), equal the
+    committed streams of tests/golden/philox_kat.json -- and so, by test_philox_kat above, the
+    oracle's Philox and, by the GPU parity tests, the kernel's."""
+    import shutil
+    import subprocess
+    import pytest
+    header = "/opt/rocm/include/rocrand/rocrand_philox4x32_10.h"
+    if not os.path.exists(header) or not shutil.which("g++"):
+        pytest.skip("rocRAND header or g++ not present")
+    exe = str(tmp_path / "rocrand_kat")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "rocrand_kat.cpp")
+    subprocess.check_call(["g++", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe, src])
+    streams = json.load(open(os.path.join(GOLDEN, "philox_kat.json")))["streams"]
+    assert len(streams) >= 3
+    args = [str(x) for s in streams for x in (s["seed"], s["env_id"], s["offset"])]
+    out = subprocess.run([exe] + args, capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert len(out) == len(streams)
+    for line, s in zip(out, streams):
+        assert [int(x) for x in line.split()] == s["u32"], s
