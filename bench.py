@@ -97,22 +97,25 @@ def cpu_baseline(actions_host, seconds=12.0):
             "one_core_value": round(one, 1)}
 
 
-def load_pmc_traffic():
-    """(HBM bytes per launch, source) from the newest committed PMC pass (profiles/hbm_traffic_*.json:
-    separate FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH doubled for gfx950), or (None, None)."""
+def load_pmc_traffic(bytes_per_launch):
+    """(HBM bytes per launch, source) from the newest committed PMC pass of THIS workload
+    (profiles/hbm_traffic_*.json: separate FETCH_SIZE / WRITE_SIZE passes of this same command,
+    FETCH doubled for gfx950; matched by its algorithmic bytes per launch), or (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "hbm_traffic_*.json")))
-    try:
-        with open(files[-1]) as f:
-            d = json.load(f)
-        src = "profiles/" + os.path.basename(files[-1])
-        if d.get("recorded"):
-            src += f" (rocprofv3 --pmc passes recorded {d['recorded']}; not measured by this run)"
-        else:
-            src += " (recorded rocprofv3 --pmc passes; not measured by this run)"
-        return d.get("hbm_bytes_per_launch"), src
-    except Exception:  # noqa: BLE001
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "hbm_traffic_*.json"))):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except Exception:  # noqa: BLE001
+            continue
+        if d.get("algorithmic_bytes_per_launch") == bytes_per_launch and (best is None or d.get("recorded", "") >= best[1].get("recorded", "")):
+            best = (f, d)
+    if best is None:
         return None, None
+    f, d = best
+    return d.get("hbm_bytes_per_launch"), (f"profiles/{os.path.basename(f)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                            f"command recorded {d.get('recorded')}; not measured by this run)")
 
 
 def self_launch(args):
@@ -278,7 +281,7 @@ def main():
         bytes_per_launch = bytes_per_env_step * n
         launch_us = med_ms * 1e3 / K
         achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
-        traffic, traffic_src = load_pmc_traffic()
+        traffic, traffic_src = load_pmc_traffic(bytes_per_launch)
         out = {
             "metric": "env-steps/sec (agent·step) at 4 096×19×19×3-snake, 1/2/4/8 GPU + CPU ref",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,

@@ -76,6 +76,7 @@ struct StepRest {
 // pk2: flag bits preloaded with the other kernel arguments
 #define PK2_SHORT_REC 1u   // move only the first 128 bytes of each record
 #define PK2_STREAM_OBS 2u  // observation stores carry the nt (streaming) hint
+#define PK2_EPB_SHIFT 8    // bits 8..15: envs (waves) per workgroup
 
 struct StepParams {
     // configuration

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // (127-254 KB contiguous) instead of single-workgroup pieces whose edge cache lines it shares with two other XCDs.
     // An incomplete last group keeps the identity mapping.  (Measured: 0.4 % less WRITE_SIZE, launch
     // time unchanged -- the envs share nothing else across workgroups.)
-    const uint32_t epb = blockDim.x >> 6;
+    const uint32_t epb = (pk2 >> PK2_EPB_SHIFT) & 0xFFu;  // = blockDim.x / 64, without the scalar-memory round trip
     uint32_t b = blockIdx.x;
     if ((b | 63u) * epb < (uint32_t)nenv) b = (b & ~63u) | ((b & 7u) << 3) | ((b >> 3) & 7u);
     const int e = (int)(b * epb) + wave;
@@ -168,8 +168,11 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // whole 1 KiB wave-instructions
     const int img_bytes = (S * K + 1023) & ~1023;
     const int occ_bytes = (n2 + 15) & ~15;
-    uint8_t* img = smem + (size_t)wave * (size_t)(img_bytes + occ_bytes);  // observation being composed
+    // the persistent tape kernel keeps a pristine copy of the background in LDS (native size only)
+    constexpr bool LDSBG = MODE == 3 && K == 1;
+    uint8_t* img = smem + (size_t)wave * (size_t)(img_bytes + occ_bytes + (LDSBG ? img_bytes : 0));  // observation being composed
     uint8_t* occ = img + img_bytes;                                        // respawn occupancy
+    uint8_t* bg = occ + occ_bytes;                                         // LDSBG: background, copied to img every step
 #ifdef MSNAKE_DBG_STAGES
     const uint32_t dbg = p.dbg_stage;  // timing-only early exits
 #define DBG_EXIT(n) if (dbg == (n)) { if (hv == 0xDEADBEEFu) hdr_g[lane] = hv + cr[0] + (uint32_t)actv; return; }
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     for (int s = 0; s < NS; ++s) cr[s] = body0_g[s * 64 + lane];
     int actv = 0;
     constexpr bool STEPS = MODE == 0 || MODE == 3;  // MODE 3: n_steps steps of an action tape in one launch
-    if (STEPS && lane < NS) actv = actions[(size_t)e * action_stride + lane];
+    if (MODE == 0 && lane < NS) actv = actions[(size_t)e * action_stride + lane];
     // adversarial rules keep a growing fruit LIST ([A]:183-185 appends dead bodies to it): entries
     // 0..63 in a VGPR like a body chunk (lane l = entry l), the complete list in HBM behind the rings
     const int fcap = (NS + NS * (n2 + 2) + 63) & ~63;
@@ -424,14 +427,26 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     uint8_t* done_t = done_out;
     msnake_info* info_t = p.info;
     uint8_t* obs_t = obs;
+    uint32_t abatch = 0;  // MODE 3: the actions of 16 tape rows
 #pragma nounroll
     for (int step_i = 0; step_i < n_steps; ++step_i) {
-    if (MODE == 3 && step_i > 0) {  // next row of the action tape; outputs advance by their strides
-        actions += (size_t)nenv * action_stride;
-        if (lane < NS) actv = actions[(size_t)e * action_stride + lane];
-        rew_t += p.scalar_step_stride; done_t += p.scalar_step_stride;
-        if (info_t) info_t += p.scalar_step_stride;
-        if (obs_t) obs_t += p.obs_step_stride;
+    // MODE 3 issues NO vector-memory load in a normal step: gfx9 has one counter for loads and
+    // stores, so waiting for a load would also wait for every observation store still in flight
+    // (those of the previous step).  Actions come 16 tape rows at a time (lane 4*j + s <- snake s at
+    // step step_i + j; one wait, and thus one store drain, per 16 steps), the background comes from
+    // its LDS copy.
+    if (MODE == 3) {
+        if (step_i > 0) {  // outputs advance by their strides
+            rew_t += p.scalar_step_stride; done_t += p.scalar_step_stride;
+            if (info_t) info_t += p.scalar_step_stride;
+            if (obs_t) obs_t += p.obs_step_stride;
+        }
+        if ((step_i & 15) == 0) {
+            const int t = step_i + (lane >> 2);
+            abatch = 0;
+            if ((lane & 3) < NS && t < n_steps)
+                abatch = (uint32_t)actions[((size_t)t * (size_t)nenv + (size_t)e) * action_stride + (lane & 3)];
+        }
     }
     // background image (black interior, white wall ring): one L1/L2-resident copy shared by every
     // wave, a whole number of 1 KiB wave-instructions so that no lane needs a predicate.
@@ -439,17 +454,28 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     //  the 16 MB of early stores clog each CU's memory pipe in front of every later access.)
     // It goes memory -> LDS directly (global_load_lds_dwordx4: lane l's 16 bytes land at
     // M0 base + 16*l), so the copy holds no data VGPRs and needs no ds_write.
-    if (obs_t) {
+    if (obs_t && (!LDSBG || step_i == 0)) {
         const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl) + lane;
+        uint8_t* dst = LDSBG ? bg : img;
         const int nk = img_bytes >> 10;
         for (int k = 0; k < nk; ++k)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tsrc + k * 64),
-                                             (__attribute__((address_space(3))) void*)(img + k * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, 0, 0);
     }
     // every load issued so far (state, actions, background) has landed past this point: the env
-    // logic needs the state right away, and the painters must find the background in LDS.  No
-    // store of this step has been issued yet, so this waits for loads only.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // logic needs the state right away, and the painters must find the background in LDS.  In MODES
+    // 0-2 no store has been issued yet, so this waits for loads only.
+    if (!LDSBG || (step_i & 15) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (MODE == 3) {
+        const int a = __shfl((int)abatch, 4 * (step_i & 15) + lane);
+        actv = lane < NS ? a : 0;
+    }
+    if (LDSBG && obs_t) {  // img <- pristine background (LDS operations of one wave execute in order)
+        wave_sync();
+        const int nk = img_bytes >> 10;
+        for (int k = 0; k < nk; ++k)
+            reinterpret_cast<uint4*>(img)[k * 64 + lane] = reinterpret_cast<const uint4*>(bg)[k * 64 + lane];
+    }
 
     if (STEPS) {
         float reward = 0.0f;
@@ -550,15 +576,19 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             }
             const uint32_t nC8 = row_shr<8>(hv, nC);
             hv = (lane >= 8 && lane < 8 + NS) ? nC8 : hv;
+            if (evmask != 0) {  // bodies of 64+ cells only
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                if ((mvmask >> s) & 1ull) {
-                    const int slot = (int)rdlane((uint32_t)nhp0, s);
-                    if (((evmask >> s) & 1u) && lane == slot)  // bodies of 64+ cells only
+                for (int s = 0; s < NS; ++s)
+                    if (((evmask >> s) & 1u) && lane == (int)rdlane((uint32_t)nhp0, s))
                         ring_g[(size_t)s * cap + rdlane((uint32_t)nohp, s)] = (uint16_t)cr[s];
-                    cr[s] = lane == slot ? rdlane((uint32_t)v_nh, s) : cr[s];
-                    store_ring_sector(s, cr[s], slot);
-                }
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {  // straight-line: a snake that does not move rewrites nothing
+                const int slot = (int)rdlane((uint32_t)nhp0, s);
+                const bool mv = (mvmask >> s) & 1ull;
+                cr[s] = (mv && lane == slot) ? rdlane((uint32_t)v_nh, s) : cr[s];
+                if (mv && ((lane ^ slot) < 16)) body0_g[s * 64 + lane] = (uint16_t)cr[s];
+            }
         } else {
         // ---- 1b. sequential snake updates (order matters: a respawn sees earlier snakes moved,
         //          a later snake can eat a fruit respawned this very step) ----------------------
@@ -655,14 +685,27 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             ln[s] = w0 >> 16; hp2[s] = w0 & 0xFFFFu;
             maxlen = ln[s] > maxlen ? ln[s] : maxlen;
         }
-        uint32_t hitl = 0;  // per-lane accumulation, bit (4*s + j)
+        uint32_t hitl = 0;      // [N]: per-lane accumulation, bit (4*s + j)
+        uint64_t hit_s[NS];     // [S]/[A]: lanes whose cell lies on snake s's head (own head slot excluded)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) hit_s[s] = 0;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const uint32_t pi = (uint32_t)(lane - (int)(wc[j] >> SN_C_HP0_SHIFT)) & 63u;  // piece index of this slot
             const bool valid = pi < ln[j];
+            if (RULES == MSNAKE_RULES_NEW_WORLD) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                hitl |= (valid && cr[j] == hd[s] && !(j == s && pi == 0)) ? (1u << (4 * s + j)) : 0u;
+                for (int s = 0; s < NS; ++s)
+                    hitl |= (valid && cr[j] == hd[s] && !(j == s && pi == 0)) ? (1u << (4 * s + j)) : 0u;
+            } else {
+                const uint64_t vmask = ballot(valid);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    uint64_t m = ballot(cr[j] == hd[s]) & vmask;
+                    if (j == s) m &= ~(1ull << (wc[j] >> SN_C_HP0_SHIFT));
+                    hit_s[s] |= m;
+                }
+            }
         }
         if (maxlen > 64) {  // bodies longer than one chunk: the rest comes from the ring
 #pragma unroll
@@ -675,7 +718,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                         const uint32_t cell = __hip_atomic_load(&ring_g[(size_t)j * cap + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                         for (int s = 0; s < NS; ++s)
-                            hitl |= (cell == hd[s]) ? (1u << (4 * s + j)) : 0u;
+                            hitl |= (cell == hd[s]) ? (1u << (4 * s + j)) : 0u;  // (all rule sets: folded in below)
                     }
                 }
         }
@@ -721,7 +764,12 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             uint32_t hitmask = 0;
 #pragma unroll
             for (int s = 0; s < NS; ++s)
-                if (ballot(((hitl >> (4 * s)) & 15u) != 0) != 0) hitmask |= 1u << s;
+                if (hit_s[s] != 0) hitmask |= 1u << s;
+            if (maxlen > 64) {  // overflow pieces were collected per lane
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    if (ballot(((hitl >> (4 * s)) & 15u) != 0) != 0) hitmask |= 1u << s;
+            }
             const uint32_t myhead = row_shl<8>(0u, hv) & 0xFFFFu;
             const bool dead = lane < NS && ((hv >> 16) == 0 || !in_grid(myhead, dim) || ((hitmask >> lane) & 1u));
             const uint32_t deadmask = (uint32_t)ballot(dead);
@@ -1134,13 +1182,21 @@ hipError_t launch_state_unpack(const StepParams& p, int rules, int env0, int cou
 // ------------------------------------------------------------------------------------------------
 template <int RULES, int NS, int K>
 static hipError_t launch_k(const StepParams& p, int mode, int epb, hipStream_t stream) {
-    const dim3 grid((unsigned)((p.nenv + epb - 1) / epb));
-    const dim3 block(64u * (unsigned)epb);
     const uint32_t pk0 = (uint32_t)p.dim | ((uint32_t)p.n_fruits << 6) | ((uint32_t)p.action_stride << 12) |
                          ((uint32_t)(p.auto_reset ? 1 : 0) << 15) | ((uint32_t)p.rest.max_steps << 16);
     const uint32_t pk1 = (uint32_t)p.S | ((uint32_t)p.rest.cap << 16);
-    const uint32_t pk2 = (p.short_rec ? PK2_SHORT_REC : 0u) | (p.rest.stream_obs ? PK2_STREAM_OBS : 0u);
-    const size_t lds = (size_t)p.lds_per_wave * (size_t)epb;
+
+    size_t lds_wave = (size_t)p.lds_per_wave;
+    if (mode == 3 && K == 1) {  // + the pristine background copy; fewer envs per workgroup if that needs it
+        lds_wave += (size_t)p.img_bytes;
+        while (epb > 1 && lds_wave * (size_t)epb > 64 * 1024) epb >>= 1;
+        if (lds_wave > 64 * 1024) return hipErrorInvalidValue;
+    }
+    const size_t lds = lds_wave * (size_t)epb;
+    const uint32_t pk2 = (p.short_rec ? PK2_SHORT_REC : 0u) | (p.rest.stream_obs ? PK2_STREAM_OBS : 0u) |
+                         ((uint32_t)epb << PK2_EPB_SHIFT);
+    const dim3 grid((unsigned)((p.nenv + epb - 1) / epb));
+    const dim3 block(64u * (unsigned)epb);
 #define MSNAKE_LAUNCH(M)                                                                                       \
     hipLaunchKernelGGL((msnake_step_kernel<RULES, NS, M, K>), grid, block, lds, stream, p.state, p.obs, p.actions, \
                        p.rest.rew, p.rest.done, p.nenv, pk0, pk1, pk2, p.rest)

@@ -25,7 +25,7 @@ not installed (TF / mpi4py / cloudpickle imports in baselines/__init__ chain).
 Usage: python tools/gen_golden.py            (rewrites tests/golden/*)
 """
 import contextlib
-import importlib.util
+
 import io
 import json
 import os
@@ -39,7 +39,7 @@ REF = "/root/reference"
 REF_SRC = os.path.join(REF, "src")
 ENVS = os.path.join(REF_SRC, "gym-snake", "gym_snake", "envs")
 CORE = os.path.join(REF_SRC, "gym-snake", "gym_snake", "core")
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+OUT = os.environ.get("MSNAKE_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 M0, M1 = 0xD2511F53, 0xCD9E8D57
 W0, W1 = 0x9E3779B9, 0xBB67AE85
@@ -122,17 +122,24 @@ def install_gym_stub():
 
 
 def load_by_path(name, path):
-    spec = importlib.util.spec_from_file_location(name, path)
-    mod = importlib.util.module_from_spec(spec)
+    """Execute the reference SOURCE TEXT of `path` as module `name`.  compile() of the text that is
+    read here, never a cached .pyc found beside it (the reference tree is untrusted and read-only:
+    a stale or planted __pycache__ entry with a matching header must not be able to define the
+    fixtures), and nothing is written back into that tree."""
+    with open(path, "r", encoding="utf-8") as f:
+        src = f.read()
+    mod = types.ModuleType(name)
+    mod.__file__ = path
     sys.modules[name] = mod
-    spec.loader.exec_module(mod)
+    exec(compile(src, path, "exec", dont_inherit=True), mod.__dict__)
     return mod
 
 
 def load_reference():
+    sys.dont_write_bytecode = True
     install_gym_stub()
-    if REF_SRC not in sys.path:
-        sys.path.insert(0, REF_SRC)  # for `from config import Config`
+    # [S] / [A] do `from config import Config`: give them the by-path module instead of a sys.path import
+    cfg = load_by_path("config", os.path.join(REF_SRC, "config.py"))
     S = load_by_path("ref_snake_multiple_test", os.path.join(ENVS, "snake_multiple_test.py"))
     A = load_by_path("ref_snake_adversarial", os.path.join(ENVS, "snake_adversarial_env.py"))
     N = load_by_path("ref_new_world", os.path.join(CORE, "new_world.py"))
@@ -147,8 +154,7 @@ def load_reference():
     sys.modules["gym_snake.core"] = core
     sys.modules["gym_snake.core.new_world"] = N
     NE = load_by_path("ref_snake_multiple_env_new", os.path.join(ENVS, "snake_multiple_env_new.py"))
-    from config import Config
-    return S, A, N, NE, Config
+    return S, A, N, NE, cfg.Config
 
 
 S_MOD, A_MOD, N_MOD, NE_MOD, Config = load_reference()

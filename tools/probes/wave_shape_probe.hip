@@ -12,7 +12,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
 
 template <int EPW, bool NT>
-__global__ __launch_bounds__(512) void probe(uint32_t* __restrict__ state, uint8_t* __restrict__ obs, int nenv, int spin,
+__global__ __launch_bounds__(1024) void probe(uint32_t* __restrict__ state, uint8_t* __restrict__ obs, int nenv, int spin,
                                              int S) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
         for (int s = 0; s < 4; ++s) printf(" %8.2f", run<EPW, NT>(state, obs, nenv, spins[s], WPB, iters)); \
         printf("\n");                                                                    \
     }
-    ROW(1, true, 8) ROW(1, true, 4) ROW(1, false, 8)
+    ROW(1, true, 16) ROW(1, true, 8) ROW(1, true, 4) ROW(1, true, 2) ROW(1, true, 1) ROW(1, false, 8)
     ROW(2, true, 8) ROW(2, true, 4) ROW(2, false, 4)
     ROW(4, true, 4) ROW(4, true, 2) ROW(4, false, 4)
     ROW(8, true, 2) ROW(8, true, 1)

@@ -52,10 +52,21 @@ step = [k for k in pmc if re.search(r"<\d+, \d+, 0, \d+>", k)]  # MODE 0 = msnak
 if step and "FETCH_SIZE" in pmc[step[0]] and "WRITE_SIZE" in pmc[step[0]]:
     k = step[0]
     fetch_kib, write_kib = pmc[k]["FETCH_SIZE"]["mean"], pmc[k]["WRITE_SIZE"]["mean"]
-    out = {"kernel": k, "fetch_size_kib_raw": fetch_kib, "write_size_kib": write_kib,
+    import datetime
+    bench = {}
+    try:
+        bench = json.load(open(os.path.join(src, "bench_plain.json")))
+    except Exception:  # noqa: BLE001
+        pass
+    out = {"kernel": k, "recorded": datetime.date.today().isoformat(),
+           "workload": bench.get("config", {}).get("workload"),
+           "algorithmic_bytes_per_launch": bench.get("roofline", {}).get("algorithmic_bytes_per_launch"),
+           "fetch_size_kib_raw": fetch_kib, "write_size_kib": write_kib,
            "fetch_correction": "x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B)",
            "hbm_bytes_per_launch": int((2 * fetch_kib + write_kib) * 1024),
            "launches": pmc[k]["WRITE_SIZE"]["n"]}
+    if out["algorithmic_bytes_per_launch"]:
+        out["traffic_over_algorithmic"] = round(out["hbm_bytes_per_launch"] / out["algorithmic_bytes_per_launch"], 4)
     json.dump(out, open(os.path.join(dst, f"hbm_traffic_{tag}.json"), "w"), indent=1)
     print(out)
 print(json.dumps({k[-40:]: {c: round(v["median"]) for c, v in d.items()} for k, d in pmc.items()}, indent=1))
