@@ -117,7 +117,26 @@ __device__ __forceinline__ bool in_grid(uint32_t cell, int dim) {
     return r >= 1 && r <= (uint32_t)dim && c >= 1 && c <= (uint32_t)dim;
 }
 
-#define HV_SET(idx, val) hv = (lane == (idx)) ? (uint32_t)(val) : hv
+// record word idx <- a wave-uniform value by v_writelane_b32, no lane mask (a `lane == idx` select
+// costs a compare plus an SGPR pair per index, and the compiler keeps all those masks live for the
+// whole kernel: 60+ SGPRs, the source of the SGPR spills of the persistent kernel).  clang has no
+// builtin for it.  val must be wave-uniform (it goes through v_readfirstlane unless it is known to
+// be).  gfx9 VALU instructions read ONE SGPR, so the lane select is an inline constant (HV_SET_C,
+// literal index) or M0 (HV_SET, computed index; the s_nop covers an index that a VALU instruction
+// produced: v_readlane -> SGPR -> lane select needs 4 wait states).
+template <int IDX>
+__device__ __forceinline__ uint32_t hv_writelane_c(uint32_t old, uint32_t val) {
+    static_assert(IDX >= 0 && IDX < 64, "lane index");
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(uni(val)), "n"(IDX));
+    return old;
+}
+__device__ __forceinline__ uint32_t hv_writelane(uint32_t old, uint32_t val, uint32_t idx) {
+    asm("s_nop 3\n\ts_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(uni(val)), "s"(uni(idx)) : "m0");
+    return old;
+}
+#define HV_SET_C(idx, val) hv = hv_writelane_c<(idx)>(hv, (uint32_t)(val))
+#define HV_SET(idx, val) hv = hv_writelane(hv, (uint32_t)(val), (uint32_t)(idx))
+#define HV_SET_DYN(idx, val) HV_SET(idx, val)
 
 typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -139,7 +158,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     constexpr int VIEWS = RULES == MSNAKE_RULES_NEW_WORLD ? NS : 3;
     constexpr int C = 3 * VIEWS;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int lane = (int)(threadIdx.x & 63u);
+    int lane = (int)(threadIdx.x & 63u);  // (not const: MODE 3 hides it from loop-invariant hoisting, see the step loop)
     const int wave = (int)uni(threadIdx.x >> 6);
     // XCD-aware env mapping: consecutive workgroup ids go round-robin to the 8 XCDs, so within
     // every aligned group of 64 workgroups XCD x takes 8 CONSECUTIVE env blocks (bits 0-2 and 3-5 of
@@ -155,24 +174,35 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 
     // pk0 = dim | n_fruits<<6 | action_stride<<12 | auto_reset<<15 | max_steps<<16 ; pk1 = S | cap<<16
     // pk2 = PK2_* flags
-    const int dim = (int)(pk0 & 63u), nf = (int)((pk0 >> 6) & 63u), action_stride = (int)((pk0 >> 12) & 7u);
-    const bool auto_reset = (pk0 >> 15) & 1u;
-    const uint32_t max_steps = pk0 >> 16;
-    const int S = (int)(pk1 & 0xFFFFu), cap = (int)(pk1 >> 16);
+    // Everything below is one or two scalar instructions away from the three preloaded words.  The
+    // persistent kernel (MODE 3) re-derives it at the top of every step from copies the compiler
+    // cannot see through, so that none of it has to stay in SGPRs (or be spilled) across the loop.
+    uint32_t pk0v = pk0, pk1v = pk1, pk2v = pk2;
+    int dim, nf, action_stride, S, cap, W, n2, img_bytes, occ_bytes;
+    bool auto_reset, short_rec;
+    uint32_t max_steps;
+    uint8_t *img, *occ, *bg;
     // inline fruits: record words FR0 .. FR0 + nf - 1 (lanes of hv)
     constexpr int FR0 = RULES == MSNAKE_RULES_NEW_WORLD ? HDR_FRUIT0_N : HDR_FRUIT0_S;
-    // snake_env / adversarial can run on the first 128 bytes of the record (no parked Philox draws)
-    const bool short_rec = RULES != MSNAKE_RULES_NEW_WORLD && (pk2 & PK2_SHORT_REC);
-    const int W = dim + 2, n2 = dim * dim;
-    // LDS image: W rows of W*K pixels (already replicated horizontally when K > 1), padded to
-    // whole 1 KiB wave-instructions
-    const int img_bytes = (S * K + 1023) & ~1023;
-    const int occ_bytes = (n2 + 15) & ~15;
     // the persistent tape kernel keeps a pristine copy of the background in LDS (native size only)
     constexpr bool LDSBG = MODE == 3 && K == 1;
-    uint8_t* img = smem + (size_t)wave * (size_t)(img_bytes + occ_bytes + (LDSBG ? img_bytes : 0));  // observation being composed
-    uint8_t* occ = img + img_bytes;                                        // respawn occupancy
-    uint8_t* bg = occ + occ_bytes;                                         // LDSBG: background, copied to img every step
+    auto unpack = [&]() {
+        dim = (int)(pk0v & 63u); nf = (int)((pk0v >> 6) & 63u); action_stride = (int)((pk0v >> 12) & 7u);
+        auto_reset = (pk0v >> 15) & 1u;
+        max_steps = pk0v >> 16;
+        S = (int)(pk1v & 0xFFFFu); cap = (int)(pk1v >> 16);
+        // snake_env / adversarial can run on the first 128 bytes of the record (no parked Philox draws)
+        short_rec = RULES != MSNAKE_RULES_NEW_WORLD && (pk2v & PK2_SHORT_REC);
+        W = dim + 2; n2 = dim * dim;
+        // LDS image: W rows of W*K pixels (already replicated horizontally when K > 1), padded to
+        // whole 1 KiB wave-instructions
+        img_bytes = (S * K + 1023) & ~1023;
+        occ_bytes = (n2 + 15) & ~15;
+        img = smem + (size_t)wave * (size_t)(img_bytes + occ_bytes + (LDSBG ? img_bytes : 0));  // observation being composed
+        occ = img + img_bytes;                                        // respawn occupancy
+        bg = occ + occ_bytes;                                         // LDSBG: background, copied to img every step
+    };
+    unpack();
 #ifdef MSNAKE_DBG_STAGES
     const uint32_t dbg = p.dbg_stage;  // timing-only early exits
 #define DBG_EXIT(n) if (dbg == (n)) { if (hv == 0xDEADBEEFu) hdr_g[lane] = hv + cr[0] + (uint32_t)actv; return; }
@@ -184,6 +214,11 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #define STAMP(k)
 #define STAMP_FLAG(v)
 #endif
+    // Section boundary for the register allocator: lane masks (`lane == k`, `lane < k`: an SGPR pair
+    // each) computed before it are not kept alive past it.  Only in the instantiations whose peak
+    // SGPR demand would otherwise spill (adversarial rules, four snakes); a no-op elsewhere.
+    constexpr bool FENCED = RULES == MSNAKE_RULES_ADVERSARIAL || NS == 4 || MODE == 3;
+#define LANE_FENCE() do { if (FENCED) asm volatile("" : "+v"(lane)); } while (0)
 
     // ---- 0. every load whose address depends only on the env index.  One allocation holds
     //         [records | chunk-0 bodies | background image | rings]: one preloaded pointer ---------
@@ -191,8 +226,19 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     uint32_t* hdr_g = reinterpret_cast<uint32_t*>(state) + (size_t)e * MSNAKE_HDR_WORDS;
     uint16_t* body0_all = reinterpret_cast<uint16_t*>(state + (size_t)nenv * (MSNAKE_HDR_WORDS * 4));
     uint16_t* body0_g = body0_all + (size_t)e * NS * 64;
-    const uint8_t* tmpl = reinterpret_cast<const uint8_t*>(body0_all + (size_t)nenv * NS * 64);
-    uint16_t* ring_g = reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl) + img_bytes) + (size_t)e * NS * cap;  // overflow rings
+    // background image and, behind it, the overflow rings (bodies longer than 64 cells only): the
+    // addresses are derived where they are needed -- the asm keeps the compiler from computing them
+    // at kernel entry and holding them in SGPRs for the whole launch
+    auto tmpl_of = [&]() -> const uint8_t* {
+        uint32_t n = (uint32_t)nenv;
+        if (MODE == 3) asm volatile("" : "+s"(n));
+        return state + (size_t)n * (MSNAKE_HDR_WORDS * 4 + NS * 128);
+    };
+    auto ring_of = [&](int s) -> uint16_t* {
+        uint32_t ee = (uint32_t)e;
+        asm volatile("" : "+s"(ee));
+        return reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl_of()) + img_bytes) + ((size_t)ee * NS + (size_t)s) * (size_t)cap;
+    };
     uint32_t hv = 0;            // THE env record: lane l holds word l; lanes FR0+f hold fruit f
     if (!short_rec || lane < MSNAKE_HDR_SHORT_WORDS) hv = hdr_g[lane];
     uint32_t cr[NS];            // cr[s], lane l: slot l of snake s's body ring; piece i sits in slot (hp0 + i) & 63
@@ -204,15 +250,22 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // adversarial rules keep a growing fruit LIST ([A]:183-185 appends dead bodies to it): entries
     // 0..63 in a VGPR like a body chunk (lane l = entry l), the complete list in HBM behind the rings
     const int fcap = (NS + NS * (n2 + 2) + 63) & ~63;
-    uint16_t* fl0_g = nullptr;
-    uint16_t* flist_g = nullptr;
+    // (addresses derived at the point of use, like the overflow rings: nothing kept in SGPRs)
+    auto fl0_of = [&]() -> uint16_t* {
+        uint32_t ee = (uint32_t)e;
+        asm volatile("" : "+s"(ee));
+        return reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl_of()) + img_bytes) + (size_t)nenv * NS * cap + (size_t)ee * 64;
+    };
+    auto flist_of = [&]() -> uint16_t* {
+        uint32_t ee = (uint32_t)e;
+        asm volatile("" : "+s"(ee));
+        return reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl_of()) + img_bytes) + (size_t)nenv * NS * cap + (size_t)nenv * 64 +
+               (size_t)ee * fcap;
+    };
     uint32_t fr = 0;
     bool fr_dirty = false;      // fr changed in this launch (wave-uniform): chunk 0 of the list is written back
     if (RULES == MSNAKE_RULES_ADVERSARIAL) {
-        uint16_t* fl0_all = reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl) + img_bytes) + (size_t)nenv * NS * cap;
-        fl0_g = fl0_all + (size_t)e * 64;
-        flist_g = fl0_all + (size_t)nenv * 64 + (size_t)e * fcap;
-        fr = fl0_g[lane];
+        fr = fl0_of()[lane];
     }
 
     // ---- RNG: randint(n) = (u32 * n) >> 32 on draw number ctr (kept in the record).  Slow paths
@@ -247,15 +300,15 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         refill_draws(ctr_lo, ctr_hi);
     };
     auto ctr_wrapped = [&](uint32_t ctr_hi) {  // once per 2^32 draws: drop both caches
-        HV_SET(HDR_CTR_HI, ctr_hi + 1);
+        HV_SET_C(HDR_CTR_HI, ctr_hi + 1);
         draws_n = 0;
-        if (PCACHE) HV_SET(HDR_PC_VALID, 0u);
+        if (PCACHE) HV_SET_C(HDR_PC_VALID, 0u);
     };
     auto randint = [&](uint32_t n) -> uint32_t {  // ensure_draws() has covered this draw
         const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
         const uint32_t u = rdlane(draws, (int)((ctr_lo - draw_base) & 63u));
         const uint32_t nlo = ctr_lo + 1;
-        HV_SET(HDR_CTR_LO, nlo);
+        HV_SET_C(HDR_CTR_LO, nlo);
         if (nlo == 0) ctr_wrapped(ctr_hi);
         return (uint32_t)(((uint64_t)u * n) >> 32);
     };
@@ -271,7 +324,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             if (i < s_len) {
                 int idx = (int)(wA & 0xFFFFu) + i - 64;
                 idx = idx >= cap ? idx - cap : idx;
-                f(i, (uint32_t)__hip_atomic_load(&ring_g[(size_t)s * cap + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                f(i, (uint32_t)__hip_atomic_load(&ring_of(s)[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
         }
     };
@@ -286,7 +339,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         if (lane < nlist) f(lane, fr);
         for (int base = 64; base < nlist; base += 64) {
             const int i = base + lane;
-            if (i < nlist) f(i, (uint32_t)__hip_atomic_load(&flist_g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (i < nlist) f(i, (uint32_t)__hip_atomic_load(&flist_of()[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
     };
     // fruits (of any rule set) lying on `cell`: how many, wave-uniform
@@ -296,7 +349,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             int n = __builtin_popcountll(ballot(lane < nlist && fr == cell));
             for (int base = 64; base < nlist; base += 64) {
                 const int i = base + lane;
-                n += __builtin_popcountll(ballot(i < nlist && (uint32_t)__hip_atomic_load(&flist_g[i < nlist ? i : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cell));
+                n += __builtin_popcountll(ballot(i < nlist && (uint32_t)__hip_atomic_load(&flist_of()[i < nlist ? i : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cell));
             }
             return n;
         }
@@ -381,14 +434,14 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 cr[s] = hd;
                 store_ring_sector(s, hd, 0);
                 if (RULES == MSNAKE_RULES_ADVERSARIAL) {  // fruits = [] then append ([A]:224-229)
-                    if (lane == s) { fr = fc; flist_g[s] = (uint16_t)fc; }
+                    if (lane == s) { fr = fc; flist_of()[s] = (uint16_t)fc; }
                     fr_dirty = true;
                 } else {
                     HV_SET(FR0 + s, fc);
                 }
             }
             const uint32_t nlo = ctr_lo + 4u * NS;
-            HV_SET(HDR_CTR_LO, nlo);
+            HV_SET_C(HDR_CTR_LO, nlo);
             if (nlo < ctr_lo) ctr_wrapped(ctr_hi);
         } else {
             ensure_draws(2u * NS + (uint32_t)nf);  // <= 40
@@ -407,18 +460,18 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             build_free();
             for (int f = 0; f < nf; ++f) {
                 const uint32_t c = safe_cell();
-                HV_SET(FR0 + f, c);
+                HV_SET_DYN(FR0 + f, c);
             }
         }
-        if (RULES == MSNAKE_RULES_ADVERSARIAL) HV_SET(HDR_NLIST, (uint32_t)NS);  // spare_fruits survives ([A]:14)
-        HV_SET(HDR_T, 0u);
-        HV_SET(HDR_FLAGS, (1u << NS) - 1u);  // alive bits set, dead_snakes empty, episode running
+        if (RULES == MSNAKE_RULES_ADVERSARIAL) HV_SET_C(HDR_NLIST, (uint32_t)NS);  // spare_fruits survives ([A]:14)
+        HV_SET_C(HDR_T, 0u);
+        HV_SET_C(HDR_FLAGS, (1u << NS) - 1u);  // alive bits set, dead_snakes empty, episode running
     };
 
     if (MODE == 1) {
         do_reset();
-        HV_SET(HDR_EP_RETURN, 0u);
-        HV_SET(HDR_EP_LEN, 0u);
+        HV_SET_C(HDR_EP_RETURN, 0u);
+        HV_SET_C(HDR_EP_LEN, 0u);
     }
 
     DBG_EXIT(1)
@@ -430,6 +483,13 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     uint32_t abatch = 0;  // MODE 3: the actions of 16 tape rows
 #pragma nounroll
     for (int step_i = 0; step_i < n_steps; ++step_i) {
+    // every `lane == k` / `lane < k` mask is an SGPR pair; seen as loop invariants they would all be
+    // computed ahead of the loop and stay live across it (or be spilled).  Redefining `lane` per
+    // iteration keeps them local to the step.
+    if (MODE == 3) {
+        asm volatile("" : "+v"(lane), "+s"(pk0v), "+s"(pk1v), "+s"(pk2v));
+        unpack();
+    }
     // MODE 3 issues NO vector-memory load in a normal step: gfx9 has one counter for loads and
     // stores, so waiting for a load would also wait for every observation store still in flight
     // (those of the previous step).  Actions come 16 tape rows at a time (lane 4*j + s <- snake s at
@@ -455,7 +515,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // It goes memory -> LDS directly (global_load_lds_dwordx4: lane l's 16 bytes land at
     // M0 base + 16*l), so the copy holds no data VGPRs and needs no ds_write.
     if (obs_t && (!LDSBG || step_i == 0)) {
-        const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl) + lane;
+        const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl_of()) + lane;
         uint8_t* dst = LDSBG ? bg : img;
         const int nk = img_bytes >> 10;
         for (int k = 0; k < nk; ++k)
@@ -535,7 +595,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     const int f = __builtin_ffs((int)m) - 1;
                     m &= m - 1;
                     const uint32_t c = safe_cell();
-                    HV_SET(FR0 + f, c);
+                    HV_SET_DYN(FR0 + f, c);
                     const uint32_t bit = (uint32_t)v_nh == c ? (1u << f) : 0u;
                     v_em = (v_moves && lane > s) ? ((v_em & ~(1u << f)) | bit) : v_em;
                 }
@@ -558,7 +618,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             }
             int nlen = v_len - pops + 1;            // insert(0, head)
             if (ballot(v_moves && nlen > cap - 1) != 0) {  // unreachable under the documented caps
-                HV_SET(HDR_ACC_ERRORS, rdlane(hv, HDR_ACC_ERRORS) + 1u);
+                HV_SET_C(HDR_ACC_ERRORS, rdlane(hv, HDR_ACC_ERRORS) + 1u);
                 nlen = nlen > cap - 1 ? cap - 1 : nlen;
             }
             // the new head takes ring slot hp0 - 1, which held piece 63; if that piece stays part of the
@@ -580,7 +640,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
                     if (((evmask >> s) & 1u) && lane == (int)rdlane((uint32_t)nhp0, s))
-                        ring_g[(size_t)s * cap + rdlane((uint32_t)nohp, s)] = (uint16_t)cr[s];
+                        ring_of(s)[rdlane((uint32_t)nohp, s)] = (uint16_t)cr[s];
             }
 #pragma unroll
             for (int s = 0; s < NS; ++s) {  // straight-line: a snake that does not move rewrites nothing
@@ -618,7 +678,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 if (len >= g) len -= 1;  // [S]:134-135
             }
             len += 1;  // insert(0, head)
-            if (len > cap - 1) { len = cap - 1; HV_SET(HDR_ACC_ERRORS, rdlane(hv, HDR_ACC_ERRORS) + 1u); }
+            if (len > cap - 1) { len = cap - 1; HV_SET_C(HDR_ACC_ERRORS, rdlane(hv, HDR_ACC_ERRORS) + 1u); }
             int ohp = (int)(w0 & 0xFFFFu);
             const int slot = ((int)(w2 >> SN_C_HP0_SHIFT) - 1) & 63;  // ring slot of the new head (held piece 63)
             const bool evict = len0 >= 64 && len >= 65;              // piece 63 becomes piece 64: to the overflow ring
@@ -629,7 +689,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #pragma unroll
             for (int j = 0; j < NS; ++j)
                 if (j == s) {
-                    if (evict && lane == slot) ring_g[(size_t)s * cap + ohp] = (uint16_t)cr[j];
+                    if (evict && lane == slot) ring_of(s)[ohp] = (uint16_t)cr[j];
                     cr[j] = lane == slot ? (uint32_t)nh : cr[j];
                     store_ring_sector(j, cr[j], slot);
                 }
@@ -642,7 +702,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     bool built = false;
                     for (int base = 0; base < nlist; base += 64) {
                         const int i = base + lane;
-                        const uint32_t c = base == 0 ? fr : (uint32_t)__hip_atomic_load(&flist_g[i < nlist ? i : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t c = base == 0 ? fr : (uint32_t)__hip_atomic_load(&flist_of()[i < nlist ? i : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         uint64_t m = ballot(i < nlist && c == (uint32_t)nh);
                         while (m) {
                             const int bit = __builtin_ffsll((long long)m) - 1;
@@ -652,10 +712,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                             const uint32_t nc = safe_cell();
                             if (base == 0 && lane == bit) fr = nc;
                             fr_dirty = fr_dirty || base == 0;
-                            if (lane == 0) flist_g[base + bit] = (uint16_t)nc;
+                            if (lane == 0) flist_of()[base + bit] = (uint16_t)nc;
                         }
                     }
-                    HV_SET(HDR_SPARE, (uint32_t)spare);
+                    HV_SET_C(HDR_SPARE, (uint32_t)spare);
                 } else {
                     ensure_draws((uint32_t)neat);
                     build_free();
@@ -664,7 +724,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                         const int f = __builtin_ffsll((long long)m) - 1;
                         m &= m - 1;
                         const uint32_t c = safe_cell();
-                        HV_SET(FR0 + f, c);
+                        HV_SET_DYN(FR0 + f, c);
                     }
                 }
             }
@@ -672,6 +732,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
 
         STAMP(2);
+        LANE_FENCE();
         DBG_EXIT(2)
         // ---- 2. head-vs-piece matrix: some piece of snake j other than s's own head lies on
         //         s's head.  [S] only needs "any j" per s; [N] needs the full matrix -------------
@@ -715,7 +776,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     if (i < (int)ln[j]) {
                         int idx = (int)hp2[j] + i - 64;
                         idx = idx >= cap ? idx - cap : idx;
-                        const uint32_t cell = __hip_atomic_load(&ring_g[(size_t)j * cap + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t cell = __hip_atomic_load(&ring_of(j)[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                         for (int s = 0; s < NS; ++s)
                             hitl |= (cell == hd[s]) ? (1u << (4 * s + j)) : 0u;  // (all rule sets: folded in below)
@@ -755,7 +816,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 if (!alive) flags |= (16u << s);  // dead_snakes, append-once
                 if (s == 0) done0 = alive;        // [N]:107 (sic)
             }
-            HV_SET(HDR_FLAGS, flags);
+            HV_SET_C(HDR_FLAGS, flags);
             if (done0) reward = -1.0f;  // [NE]:39-40
             done = (t >= max_steps) || done0;
             num_alive = NS - __builtin_popcount((flags >> 4) & 15u);
@@ -786,14 +847,14 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                         if (lane >= nlist && lane < nlist + len_s) fr = moved;
                         fr_dirty = true;
                         for_each_piece(s, cr[s], hp2[s], wc[s], len_s, [&](int i, uint32_t cell) {
-                            flist_g[nlist + i] = (uint16_t)cell;
+                            flist_of()[nlist + i] = (uint16_t)cell;
                         });
                         nlist += len_s;
                         spare += len_s * len_s;
                     }
                 }
-                HV_SET(HDR_NLIST, (uint32_t)nlist);
-                HV_SET(HDR_SPARE, (uint32_t)spare);
+                HV_SET_C(HDR_NLIST, (uint32_t)nlist);
+                HV_SET_C(HDR_SPARE, (uint32_t)spare);
             }
             hv = dead ? (hv & 0xFFFFu) : hv;  // snakes[idx] = []
             const bool main_dead = deadmask & 1u;
@@ -801,11 +862,13 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             done = (t >= max_steps) || main_dead;
             num_alive = NS - __builtin_popcount(deadmask);
         }
-        HV_SET(HDR_T, t);
+        HV_SET_C(HDR_T, t);
 
         STAMP(3);
+        LANE_FENCE();
         DBG_EXIT(4)
         // ---- 4. vec layer: episode statistics and auto reset -----------------------------------
+        LANE_FENCE();
         float ep_ret = __uint_as_float(rdlane(hv, HDR_EP_RETURN)) + reward;
         uint32_t ep_len = rdlane(hv, HDR_EP_LEN) + 1;
         float out_ret = 0.0f;
@@ -822,15 +885,15 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 const bool carry = ballot(lane == HDR_ACC_LEN && hv < ep_len) != 0;  // 64-bit length total
                 if (carry && lane == HDR_ACC_LEN_HI) hv += 1u;
                 if (lane == HDR_ACC_RETURN) hv += (uint32_t)(int)ep_ret;
-                HV_SET(HDR_FLAGS, fl | HDR_FLAG_FINISHED);
+                HV_SET_C(HDR_FLAGS, fl | HDR_FLAG_FINISHED);
             }
             if (auto_reset) {
                 ep_ret = 0.0f; ep_len = 0;
                 do_reset();
             }
         }
-        HV_SET(HDR_EP_RETURN, __float_as_uint(ep_ret));
-        HV_SET(HDR_EP_LEN, ep_len);
+        HV_SET_C(HDR_EP_RETURN, __float_as_uint(ep_ret));
+        HV_SET_C(HDR_EP_LEN, ep_len);
         STAMP(4);
         STAMP_FLAG((unsigned long long)(any_eat ? 1 : 0) | (done ? 2ull : 0ull));
         if (lane == 0) {
@@ -845,6 +908,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     }
 
     // ---- 6. paint the observation over the background, in reference order ----------------------
+    LANE_FENCE();
     if (obs_t) {
         wave_sync();
         uint8_t* px = img;
@@ -948,14 +1012,18 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             if (draws_n == 64 && off + HDR_PC_N <= 64u) {
                 const uint32_t sh = (uint32_t)__shfl((int)draws, lane - HDR_PC_FIRST + (int)off);
                 hv = lane >= HDR_PC_FIRST ? sh : hv;
-                HV_SET(HDR_PC_BASE, ctr_lo);
-                HV_SET(HDR_PC_VALID, 1u);
+                HV_SET_C(HDR_PC_BASE, ctr_lo);
+                HV_SET_C(HDR_PC_VALID, 1u);
             } else {
-                HV_SET(HDR_PC_VALID, 0u);
+                HV_SET_C(HDR_PC_VALID, 0u);
             }
         }
-        if (!short_rec || lane < MSNAKE_HDR_SHORT_WORDS) hdr_g[lane] = hv;
-        if (RULES == MSNAKE_RULES_ADVERSARIAL && fr_dirty) fl0_g[lane] = (uint16_t)fr;
+        if (!short_rec || lane < MSNAKE_HDR_SHORT_WORDS) {
+            uint32_t ee = (uint32_t)e;
+            if (MODE == 3) asm volatile("" : "+s"(ee));  // (the pointer is not held across the step loop)
+            (reinterpret_cast<uint32_t*>(state) + (size_t)ee * MSNAKE_HDR_WORDS)[lane] = hv;
+        }
+        if (RULES == MSNAKE_RULES_ADVERSARIAL && fr_dirty) fl0_of()[lane] = (uint16_t)fr;
     }
 
 }
@@ -1119,9 +1187,9 @@ __global__ __launch_bounds__(256) void msnake_state_unpack_kernel(StateView v, i
     //      state and stay; every other word, the parked Philox draws included, is cleared)
     uint32_t* h = v.hdr + (size_t)e * MSNAKE_HDR_WORDS;
     uint32_t hv = (lane >= HDR_ACC_EPISODES && lane <= HDR_ACC_LEN_HI) ? h[lane] : 0u;
-    HV_SET(HDR_T, in[0]); HV_SET(HDR_CTR_LO, in[1]); HV_SET(HDR_CTR_HI, in[2]); HV_SET(HDR_SPARE, in[3]);
-    HV_SET(HDR_EP_LEN, in[4]); HV_SET(HDR_EP_RETURN, in[5]);
-    if (adv) HV_SET(HDR_NLIST, nfr);
+    HV_SET_C(HDR_T, in[0]); HV_SET_C(HDR_CTR_LO, in[1]); HV_SET_C(HDR_CTR_HI, in[2]); HV_SET_C(HDR_SPARE, in[3]);
+    HV_SET_C(HDR_EP_LEN, in[4]); HV_SET_C(HDR_EP_RETURN, in[5]);
+    if (adv) HV_SET_C(HDR_NLIST, nfr);
     k = 8;
     const int fr0 = nw ? HDR_FRUIT0_N : HDR_FRUIT0_S;
     for (int f = lane; f < nfr; f += 64) {
@@ -1133,7 +1201,7 @@ __global__ __launch_bounds__(256) void msnake_state_unpack_kernel(StateView v, i
     }
     if (!adv)
         for (int f = 0; f < nfr; ++f)
-            HV_SET(fr0 + f, ((uint32_t)(in[k + 2 * f] + 1) << 8) | (uint32_t)(in[k + 2 * f + 1] + 1));
+            HV_SET_DYN(fr0 + f, ((uint32_t)(in[k + 2 * f] + 1) << 8) | (uint32_t)(in[k + 2 * f + 1] + 1));
     k += 2LL * nfr;
     uint32_t flags = 0;
     for (int s = 0; s < v.ns; ++s) {
@@ -1153,7 +1221,7 @@ __global__ __launch_bounds__(256) void msnake_state_unpack_kernel(StateView v, i
         HV_SET(SN_C(s), headc | ((uint32_t)vel << 16));
         k += 6 + 2LL * len;
     }
-    HV_SET(HDR_FLAGS, flags);
+    HV_SET_C(HDR_FLAGS, flags);
     h[lane] = hv;
 }
 
