@@ -76,6 +76,7 @@ struct StepRest {
 // pk2: flag bits preloaded with the other kernel arguments
 #define PK2_SHORT_REC 1u   // move only the first 128 bytes of each record
 #define PK2_STREAM_OBS 2u  // observation stores carry the nt (streaming) hint
+#define PK2_STREAM_TAPE 4u // same for the persistent tape kernel (msnake_rollout_tape)
 #define PK2_EPB_SHIFT 8    // bits 8..15: envs (waves) per workgroup
 
 struct StepParams {
@@ -86,6 +87,7 @@ struct StepParams {
     int32_t action_stride;
     int32_t obs_scale;     // fused WarpFrame replication factor (1, 4 or 7)
     int32_t short_rec;     // 1: the step moves only the first 128 bytes of each record
+    int32_t stream_tape;   // 1: msnake_rollout_tape stores observations with the nt hint (set per call)
     // state (HBM, owned by the handle): ONE allocation
     //   [hdr: nenv x 256 B][body0: nenv x n_snakes x 128 B][tmpl: img_bytes][ovf: nenv x n_snakes x cap x 2 B]
     //   adversarial only: [fl0: nenv x 128 B][flist: nenv x fcap x 2 B] (fruit list chunk 0 / complete)

@@ -966,7 +966,12 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             //         S%16 bytes go singly.
             uint8_t* obs_env = obs_t + (size_t)e * S;
             const int nfull = S >> 4;
-            if (MODE != 3 && (pk2 & PK2_STREAM_OBS)) {  // streaming (nt) stores, see msnake_capi.hip: obs_store_policy
+            // One LDS read -> one store per KiB, in a plain loop.  (Measured and rejected, same box:
+            // all LDS reads first and then the stores back to back -- fewer instructions, but 7.65
+            // instead of 6.9 us per launch at 4 096 envs: a wave's burst of stores sits in its CU's
+            // memory pipe ahead of the state loads of the waves that start later; pausing between
+            // the stores (s_sleep) or storing the last KiB first changes nothing.)
+            if (pk2 & (MODE == 3 ? PK2_STREAM_TAPE : PK2_STREAM_OBS)) {  // streaming (nt) stores, see msnake_capi.hip: obs_store_policy
                 for (int k = lane; k < nfull; k += 64)
                     __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(img)[k], reinterpret_cast<u32x4_unaligned*>(obs_env + 16 * k));
             } else {
@@ -1262,6 +1267,7 @@ static hipError_t launch_k(const StepParams& p, int mode, int epb, hipStream_t s
     }
     const size_t lds = lds_wave * (size_t)epb;
     const uint32_t pk2 = (p.short_rec ? PK2_SHORT_REC : 0u) | (p.rest.stream_obs ? PK2_STREAM_OBS : 0u) |
+                         (p.stream_tape ? PK2_STREAM_TAPE : 0u) | 
                          ((uint32_t)epb << PK2_EPB_SHIFT);
     const dim3 grid((unsigned)((p.nenv + epb - 1) / epb));
     const dim3 block(64u * (unsigned)epb);
