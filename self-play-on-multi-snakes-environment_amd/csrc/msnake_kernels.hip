@@ -514,6 +514,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     //  the 16 MB of early stores clog each CU's memory pipe in front of every later access.)
     // It goes memory -> LDS directly (global_load_lds_dwordx4: lane l's 16 bytes land at
     // M0 base + 16*l), so the copy holds no data VGPRs and needs no ds_write.
+    // (Issuing it only after the state has arrived, so that no wave's state load queues behind
+    //  another wave's 4 KB of background, was measured too: 6.88 instead of 6.79 us, same box.)
     if (obs_t && (!LDSBG || step_i == 0)) {
         const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl_of()) + lane;
         uint8_t* dst = LDSBG ? bg : img;
