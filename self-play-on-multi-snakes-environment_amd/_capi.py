@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsnake.so")
+# MSNAKE_LIB: another build of the same library (kernel A/B runs on one box); never a different backend
+LIB_PATH = os.environ.get("MSNAKE_LIB") or os.path.join(_HERE, "libmsnake.so")
 
 RULES = {"snake_env": 0, "new_world": 1, "adversarial": 2}
 RULE_NAMES = {v: k for k, v in RULES.items()}

@@ -540,6 +540,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     }
 
     if (STEPS) {
+        LANE_FENCE();
         float reward = 0.0f;
         // ---- 1. snake updates.  Fast path: all snakes at once on the VALU, lane s = snake s.
         //         Valid whenever no moving snake eats (then no fruit respawns, so the updates do
@@ -656,6 +657,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         //          a later snake can eat a fruit respawned this very step) ----------------------
 #pragma nounroll
         for (int s = 0; s < NS; ++s) {  // a real loop: the slow path below exists once in the code
+            LANE_FENCE();
             const uint32_t w0 = rdlane(hv, SN_A(s)), w2 = rdlane(hv, SN_C(s));
             int len = (int)(w0 >> 16);
             if (len == 0) continue;

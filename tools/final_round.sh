@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: everything the round's evidence under profiles/ comes from, on ONE box:
+# parity suite, bench at the driver's step count and at 1 024 steps, rocprofv3 stats + PMC passes at
+# 4 096 and 262 144 envs, the persistent-tape profile, the SURVEY 8(d) sweep and the 2-rank rehearsal.
+# usage: tools/final_round.sh <tag>
+set -u
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+bash tools/gpu_check.sh $TAG || exit 1
+bash tools/profile_round.sh ${TAG}_4096 4096 1024 > $OUT/prof4096.log 2>&1
+echo "profile 4096 done"
+bash tools/profile_round.sh ${TAG}_262144 262144 64 > $OUT/prof262144.log 2>&1
+echo "profile 262144 done"
+bash tools/profile_rollout.sh $TAG > $OUT/prof_rollout.log 2>&1
+echo "profile rollout done"
+python tools/sweep.py > $OUT/sweep.json 2> $OUT/sweep.err
+echo "sweep done"
+MSNAKE_BENCH_ONE_DEVICE=1 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --steps 1024 --warmup 64 > $OUT/bench_2rank_gloo_one_device.json 2> $OUT/bench_2rank.err
+cut -c1-300 $OUT/bench_2rank_gloo_one_device.json
