@@ -975,6 +975,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             // instead of 6.9 us per launch at 4 096 envs: a wave's burst of stores sits in its CU's
             // memory pipe ahead of the state loads of the waves that start later; pausing between
             // the stores (s_sleep) or storing the last KiB first changes nothing.)
+            // (Streaming stores for the interior and plain ones for the first / last 128 bytes of each
+            //  image, so that the edge cache lines two neighbouring images share meet in L2: WRITE_SIZE
+            //  drops from 4 424 to 4 189 B per env at 262 144 envs, and the launch takes 387 instead of
+            //  206-232 us -- mixing the two store kinds on one region is ruinous.  Rejected.)
             if (pk2 & (MODE == 3 ? PK2_STREAM_TAPE : PK2_STREAM_OBS)) {  // streaming (nt) stores, see msnake_capi.hip: obs_store_policy
                 for (int k = lane; k < nfull; k += 64)
                     __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(img)[k], reinterpret_cast<u32x4_unaligned*>(obs_env + 16 * k));
