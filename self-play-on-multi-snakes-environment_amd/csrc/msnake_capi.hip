@@ -123,6 +123,9 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
     }
     if (cfg->max_steps < 1 || cfg->max_steps > 60000)
         return fail(MSNAKE_E_ARG, "max_steps must be in [1, 60000]");
+    if ((uint64_t)cfg->num_envs * (uint64_t)(MSNAKE_HDR_WORDS * 4 + MSNAKE_MAX_SNAKES * 128) >= (1ull << 32))
+        return fail(MSNAKE_E_ARG, "num_envs %d: records and body rings of one handle must stay below 4 GB (the kernel "
+                                  "addresses them with 32-bit offsets); use several handles", cfg->num_envs);
     if (cfg->obs_scale != 1 && cfg->obs_scale != 4 && cfg->obs_scale != 7)
         return fail(MSNAKE_E_ARG, "obs_scale must be 1, 4 (21->84) or 7 (12->84), got %d", cfg->obs_scale);
 

@@ -142,6 +142,53 @@ typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
 
+// One snake pixel in the C = 3*VIEWS interleaved channels: view v shows snake J as "self" when v == J.
+// body: self (0,204,0) / other (0,51,204); head: self (191,242,191) / other (128,154,230)
+// ([S]:24-33,46-50, [N] Color :256-274).  The C bytes are compile-time constants per (J, head?): they
+// are stored as whole words selected by ONE per-lane condition instead of C byte-wise selects.
+template <int J, int VIEWS>
+__host__ __device__ __forceinline__ constexpr uint8_t pix_byte(bool head, int b) {
+    const bool self = (b / 3) == J;
+    const int ch = b % 3;
+    return head ? (self ? (ch == 1 ? 242 : 191) : (ch == 0 ? 128 : ch == 1 ? 154 : 230))
+                : (self ? (ch == 1 ? 204 : 0) : (ch == 0 ? 0 : ch == 1 ? 51 : 204));
+}
+template <int J, int VIEWS, int NB>
+__host__ __device__ __forceinline__ constexpr uint64_t pix_word(bool head, int first) {  // bytes first .. first+NB-1, little endian
+    uint64_t w = 0;
+    for (int b = 0; b < NB; ++b) w |= (uint64_t)pix_byte<J, VIEWS>(head, first + b) << (8 * b);
+    return w;
+}
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
+template <int J, int VIEWS>
+__device__ __forceinline__ void paint_pixel(uint8_t* p, bool head) {
+    constexpr int C = 3 * VIEWS;
+    if constexpr (C == 3) {
+        constexpr uint16_t H = (uint16_t)pix_word<J, VIEWS, 2>(true, 0), B = (uint16_t)pix_word<J, VIEWS, 2>(false, 0);
+        constexpr uint8_t H2 = pix_byte<J, VIEWS>(true, 2), B2 = pix_byte<J, VIEWS>(false, 2);
+        *reinterpret_cast<u16_unaligned*>(p) = head ? H : B;
+        p[2] = head ? H2 : B2;
+    } else if constexpr (C == 6) {
+        constexpr uint32_t H = (uint32_t)pix_word<J, VIEWS, 4>(true, 0), B = (uint32_t)pix_word<J, VIEWS, 4>(false, 0);
+        constexpr uint16_t H4 = (uint16_t)pix_word<J, VIEWS, 2>(true, 4), B4 = (uint16_t)pix_word<J, VIEWS, 2>(false, 4);
+        *reinterpret_cast<u32_unaligned*>(p) = head ? H : B;
+        *reinterpret_cast<u16_unaligned*>(p + 4) = head ? H4 : B4;
+    } else if constexpr (C == 9) {
+        constexpr uint64_t H = pix_word<J, VIEWS, 8>(true, 0), B = pix_word<J, VIEWS, 8>(false, 0);
+        constexpr uint8_t H8 = pix_byte<J, VIEWS>(true, 8), B8 = pix_byte<J, VIEWS>(false, 8);
+        *reinterpret_cast<u64_unaligned*>(p) = head ? H : B;
+        p[8] = head ? H8 : B8;
+    } else {
+        static_assert(C == 12, "views");
+        constexpr uint64_t H = pix_word<J, VIEWS, 8>(true, 0), B = pix_word<J, VIEWS, 8>(false, 0);
+        constexpr uint32_t H8 = (uint32_t)pix_word<J, VIEWS, 4>(true, 8), B8 = (uint32_t)pix_word<J, VIEWS, 4>(false, 8);
+        *reinterpret_cast<u64_unaligned*>(p) = head ? H : B;
+        *reinterpret_cast<u32_unaligned*>(p + 8) = head ? H8 : B8;
+    }
+}
+
 // MODE 0: step, 1: reset every env (msnake_reset), 2: render only (msnake_render), 3: n_steps steps of
 //      an action tape in ONE launch with the env kept in registers (msnake_rollout_tape)
 // K: integer pixel replication of the observation fused into the copy-out (the reference's WarpFrame,
@@ -223,30 +270,33 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // ---- 0. every load whose address depends only on the env index.  One allocation holds
     //         [records | chunk-0 bodies | background image | rings]: one preloaded pointer ---------
     STAMP(0);
-    uint32_t* hdr_g = reinterpret_cast<uint32_t*>(state) + (size_t)e * MSNAKE_HDR_WORDS;
-    uint16_t* body0_all = reinterpret_cast<uint16_t*>(state + (size_t)nenv * (MSNAKE_HDR_WORDS * 4));
-    uint16_t* body0_g = body0_all + (size_t)e * NS * 64;
+    // (byte offsets in 32 bits: records + body rings of a handle stay below 4 GB, msnake_create checks)
+    uint32_t* hdr_g = reinterpret_cast<uint32_t*>(state + (uint32_t)e * (uint32_t)(MSNAKE_HDR_WORDS * 4));
+    uint16_t* body0_g = reinterpret_cast<uint16_t*>(state + ((uint32_t)nenv * (uint32_t)(MSNAKE_HDR_WORDS * 4) +
+                                                             (uint32_t)e * (uint32_t)(NS * 128)));
     // background image and, behind it, the overflow rings (bodies longer than 64 cells only): the
     // addresses are derived where they are needed -- the asm keeps the compiler from computing them
     // at kernel entry and holding them in SGPRs for the whole launch
     auto tmpl_of = [&]() -> const uint8_t* {
         uint32_t n = (uint32_t)nenv;
         if (MODE == 3) asm volatile("" : "+s"(n));
-        return state + (size_t)n * (MSNAKE_HDR_WORDS * 4 + NS * 128);
+        return state + n * (uint32_t)(MSNAKE_HDR_WORDS * 4 + NS * 128);
     };
     auto ring_of = [&](int s) -> uint16_t* {
         uint32_t ee = (uint32_t)e;
         asm volatile("" : "+s"(ee));
         return reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl_of()) + img_bytes) + ((size_t)ee * NS + (size_t)s) * (size_t)cap;
     };
-    uint32_t hv = 0;            // THE env record: lane l holds word l; lanes FR0+f hold fruit f
-    if (!short_rec || lane < MSNAKE_HDR_SHORT_WORDS) hv = hdr_g[lane];
+    // THE env record: lane l holds word l; lanes FR0+f hold fruit f.  Short record: lanes 32..63 re-read
+    // words 0..31 (the same cache line: no extra traffic, no exec-mask juggling) and are zeroed
+    uint32_t hv = hdr_g[short_rec ? (lane & (MSNAKE_HDR_SHORT_WORDS - 1)) : lane];
+    hv = (short_rec && lane >= MSNAKE_HDR_SHORT_WORDS) ? 0u : hv;
     uint32_t cr[NS];            // cr[s], lane l: slot l of snake s's body ring; piece i sits in slot (hp0 + i) & 63
 #pragma unroll
     for (int s = 0; s < NS; ++s) cr[s] = body0_g[s * 64 + lane];
     int actv = 0;
     constexpr bool STEPS = MODE == 0 || MODE == 3;  // MODE 3: n_steps steps of an action tape in one launch
-    if (MODE == 0 && lane < NS) actv = actions[(size_t)e * action_stride + lane];
+    if (MODE == 0 && lane < NS) actv = actions[(uint32_t)e * (uint32_t)action_stride + (uint32_t)lane];
     // adversarial rules keep a growing fruit LIST ([A]:183-185 appends dead bodies to it): entries
     // 0..63 in a VGPR like a body chunk (lane l = entry l), the complete list in HBM behind the rings
     const int fcap = (NS + NS * (n2 + 2) + 63) & ~63;
@@ -520,9 +570,21 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl_of()) + lane;
         uint8_t* dst = LDSBG ? bg : img;
         const int nk = img_bytes >> 10;
-        for (int k = 0; k < nk; ++k)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tsrc + k * 64),
-                                             (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, 0, 0);
+#define MSNAKE_GP(k) ((const __attribute__((address_space(1))) void*)(tsrc + (k) * 64))
+#define MSNAKE_LP(k) ((__attribute__((address_space(3))) void*)(dst + (k) * 1024))
+        if (nk == 4) {  // the 21x21x9 image: one address pair, the instruction offset moves both sides
+            __builtin_amdgcn_global_load_lds(MSNAKE_GP(0), MSNAKE_LP(0), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(MSNAKE_GP(0), MSNAKE_LP(0), 16, 1024, 0);
+            __builtin_amdgcn_global_load_lds(MSNAKE_GP(0), MSNAKE_LP(0), 16, 2048, 0);
+            __builtin_amdgcn_global_load_lds(MSNAKE_GP(0), MSNAKE_LP(0), 16, 3072, 0);
+        } else if (nk == 2) {  // 12x12x9
+            __builtin_amdgcn_global_load_lds(MSNAKE_GP(0), MSNAKE_LP(0), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(MSNAKE_GP(0), MSNAKE_LP(0), 16, 1024, 0);
+        } else {
+            for (int k = 0; k < nk; ++k) __builtin_amdgcn_global_load_lds(MSNAKE_GP(k), MSNAKE_LP(k), 16, 0, 0);
+        }
+#undef MSNAKE_GP
+#undef MSNAKE_LP
     }
     // every load issued so far (state, actions, background) has landed past this point: the env
     // logic needs the state right away, and the painters must find the background in LDS.  In MODES
@@ -940,7 +1002,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
         // snakes in index order, head over body ([S]:46-50, draw_snake :24-33); LDS writes of one
         // wave execute in program order, which is what makes later painters win
-        const uint32_t flags = rdlane(hv, HDR_FLAGS);
+        const uint32_t flags = RULES == MSNAKE_RULES_NEW_WORLD ? rdlane(hv, HDR_FLAGS) : 0u;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const uint32_t w0 = rdlane(hv, SN_A(j));
@@ -948,17 +1010,15 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             for_each_piece(j, cr[j], w0, rdlane(hv, SN_C(j)), (int)(w0 >> 16), [&](int i, uint32_t cell) {
                 if (!in_grid(cell, dim)) return;
                 const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * (C * K);
-                const bool hd1 = i == 0;
 #pragma unroll
-                for (int k = 0; k < K; ++k)
-#pragma unroll
-                    for (int v = 0; v < VIEWS; ++v) {
-                        // body/head: self green (0,204,0)/(191,242,191), other blue (0,51,204)/(128,154,230)
-                        const bool self = v == j;
-                        px[off + k * C + 3 * v + 0] = hd1 ? (self ? 191 : 128) : 0;
-                        px[off + k * C + 3 * v + 1] = hd1 ? (self ? 242 : 154) : (self ? 204 : 51);
-                        px[off + k * C + 3 * v + 2] = hd1 ? (self ? 191 : 230) : (self ? 0 : 204);
-                    }
+                for (int k = 0; k < K; ++k) {
+                    uint8_t* q = px + off + k * C;
+                    // (j is a constant after unrolling: one of the four calls remains)
+                    if (j == 0) paint_pixel<0, VIEWS>(q, i == 0);
+                    else if (j == 1) paint_pixel<1, VIEWS>(q, i == 0);
+                    else if (j == 2) paint_pixel<2, VIEWS>(q, i == 0);
+                    else paint_pixel<3, VIEWS>(q, i == 0);
+                }
             });
         }
         wave_sync();
