@@ -141,6 +141,9 @@ int msnake_rollout_tape(msnake_handle h, const int32_t* actions_dev, int32_t act
  *  [0] t  [1] ctr_lo  [2] ctr_hi  [3] spare_fruits  [4] ep_len  [5] ep_return (f32 bits)
  *  [6] n_fruits_cur  [7] n_snakes, then n_fruits_cur x (c0,c1), then per snake:
  *  len, v0, v1, grow_to, alive, in_dead, len x (c0,c1) head first.
+ * Heads and the entries of the adversarial fruit list lie in [-1, dim] (one step outside the grid is
+ * where the reference can put them); body pieces behind the head and the fruits of snake_env /
+ * new_world lie inside the grid [0, dim).  Anything else is MSNAKE_E_STATE.
  * msnake_get_state returns the number of words needed/written (>0) or a negative error. */
 int msnake_get_state(msnake_handle h, int32_t env, int32_t* words, int32_t cap);
 int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t n);

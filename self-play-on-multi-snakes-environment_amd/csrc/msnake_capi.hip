@@ -83,7 +83,7 @@ const char* state_reason(uint32_t code) {
         case 1: return "state buffer too short / truncated";
         case 2: return "snake count differs from the handle's";
         case 3: return "fruit count differs from the handle's (or exceeds the fruit-list capacity)";
-        case 4: return "a cell lies outside [-1, dim]";
+        case 4: return "a cell lies outside [-1, dim], or a body piece behind the head outside the grid";
         case 5: return "a body length is outside [0, capacity]";
         default: return "malformed state";
     }

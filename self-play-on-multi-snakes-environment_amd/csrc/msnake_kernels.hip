@@ -992,7 +992,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             });
         } else if (lane >= FR0 && lane < FR0 + nf) {
             const uint32_t cell = hv & 0xFFFFu;
-            if (in_grid(cell, dim)) {
+            // (inline fruits are always inside the grid: resets and respawns place them there and
+            //  msnake_set_state refuses others; MODE 2 renders freshly installed states and keeps the clip)
+            if (MODE != 2 || in_grid(cell, dim)) {
                 const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * (C * K);
 #pragma unroll
                 for (int k = 0; k < K; ++k)
@@ -1008,7 +1010,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             const uint32_t w0 = rdlane(hv, SN_A(j));
             if (RULES == MSNAKE_RULES_NEW_WORLD && !((flags >> j) & 1u)) continue;  // [N]:219
             for_each_piece(j, cr[j], w0, rdlane(hv, SN_C(j)), (int)(w0 >> 16), [&](int i, uint32_t cell) {
-                if (!in_grid(cell, dim)) return;
+                // Only a HEAD can lie outside the grid (msnake_set_state refuses anything else), and after
+                // a step or a reset no live snake's head does ([S]:147-164 / [N]:117-119 clear it): the
+                // clip against the wall ring is needed only when a freshly installed state is rendered.
+                if (MODE == 2 && !in_grid(cell, dim)) return;
                 const int off = ((int)(cell >> 8) * W + (int)(cell & 255u)) * (C * K);
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
@@ -1235,7 +1240,12 @@ __global__ __launch_bounds__(256) void msnake_state_unpack_kernel(StateView v, i
     long long k = 8;
     if (!bad) {
         bool okc = true;
-        for (int f = lane; f < nfr; f += 64) okc = okc && cell_ok(in[k + 2 * f], in[k + 2 * f + 1]);
+        for (int f = lane; f < nfr; f += 64) {
+            const int c0 = in[k + 2 * f], c1 = in[k + 2 * f + 1];
+            // the adversarial fruit list may hold the off-grid head of a dead snake ([A]:183-185); the inline
+            // fruits of the other rule sets are only ever placed inside the grid
+            okc = okc && (adv ? cell_ok(c0, c1) : (c0 >= 0 && c0 < v.dim && c1 >= 0 && c1 < v.dim));
+        }
         if (__builtin_amdgcn_ballot_w64(!okc) != 0) bad = MSNAKE_ST_CELL;
         k += 2LL * nfr;
     }
@@ -1245,7 +1255,12 @@ __global__ __launch_bounds__(256) void msnake_state_unpack_kernel(StateView v, i
         if (len < 0 || len > v.cap - 2) { bad = MSNAKE_ST_LEN; break; }
         if (n < k + 6 + 2LL * len) { bad = MSNAKE_ST_SHORT; break; }
         bool okc = true;
-        for (int i = lane; i < len; i += 64) okc = okc && cell_ok(in[k + 6 + 2LL * i], in[k + 6 + 2LL * i + 1]);
+        for (int i = lane; i < len; i += 64) {
+            const int c0 = in[k + 6 + 2LL * i], c1 = in[k + 6 + 2LL * i + 1];
+            okc = okc && cell_ok(c0, c1);
+            // only a head may be one step outside the grid (where a reference snake can be, for one step)
+            if (i > 0) okc = okc && c0 >= 0 && c0 < v.dim && c1 >= 0 && c1 < v.dim;
+        }
         if (__builtin_amdgcn_ballot_w64(!okc) != 0) { bad = MSNAKE_ST_CELL; break; }
         k += 6 + 2LL * len;
     }
