@@ -18,5 +18,5 @@ bash tools/profile_rollout.sh $TAG > $OUT/prof_rollout.log 2>&1
 echo "profile rollout done"
 python tools/sweep.py > $OUT/sweep.json 2> $OUT/sweep.err
 echo "sweep done"
-MSNAKE_BENCH_ONE_DEVICE=1 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --steps 1024 --warmup 64 > $OUT/bench_2rank_gloo_one_device.json 2> $OUT/bench_2rank.err
+MSNAKE_BENCH_ONE_DEVICE=1 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --steps 1024 --warmup 64 2> $OUT/bench_2rank.err | grep "^{\"metric\"" > $OUT/bench_2rank_gloo_one_device.json
 cut -c1-300 $OUT/bench_2rank_gloo_one_device.json
