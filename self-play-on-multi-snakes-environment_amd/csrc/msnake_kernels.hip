@@ -633,7 +633,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
         v_em = v_moves ? v_em : 0u;
         STAMP(1);
-        const uint64_t mvmask = ballot(v_moves);
+        // (ballots of plain compares are the compares themselves; a ballot of a compound bool costs a
+        //  select and a second compare on top of the mask arithmetic)
+        const uint64_t mvmask = ballot(lane < NS) & ballot(v_len > 0) &
+                                (RULES == MSNAKE_RULES_NEW_WORLD ? ~0ull : ballot(v_nvel != 0));
         bool any_eat = ballot(v_em != 0) != 0;
         if (RULES == MSNAKE_RULES_ADVERSARIAL) {
 #pragma unroll
@@ -682,16 +685,22 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 pops = v_len >= v_grow ? 1 : 0;     // [A]:134-135 (eating steps take the loop below)
             }
             int nlen = v_len - pops + 1;            // insert(0, head)
-            if (ballot(v_moves && nlen > cap - 1) != 0) {  // unreachable under the documented caps
-                HV_SET_C(HDR_ACC_ERRORS, rdlane(hv, HDR_ACC_ERRORS) + 1u);
-                nlen = nlen > cap - 1 ? cap - 1 : nlen;
+            // bodies of 64+ cells (never under random play): capacity guard and eviction, behind ONE test
+            const uint64_t bigmask = ballot(nlen >= 64) & mvmask;
+            uint32_t evmask = 0;
+            bool v_evict = false;
+            if (bigmask != 0) {
+                if (ballot(v_moves && nlen > cap - 1) != 0) {  // unreachable under the documented caps
+                    HV_SET_C(HDR_ACC_ERRORS, rdlane(hv, HDR_ACC_ERRORS) + 1u);
+                    nlen = nlen > cap - 1 ? cap - 1 : nlen;
+                }
+                // the new head takes ring slot hp0 - 1, which held piece 63; if that piece stays part of the
+                // body (it becomes piece 64) it moves to the front of the overflow ring first
+                v_evict = v_moves && v_len >= 64 && nlen >= 65;
+                evmask = (uint32_t)ballot(v_evict);
             }
-            // the new head takes ring slot hp0 - 1, which held piece 63; if that piece stays part of the
-            // body (it becomes piece 64) it moves to the front of the overflow ring first
             const int nhp0 = (v_hp0 - 1) & 63;
-            const bool v_evict = v_moves && v_len >= 64 && nlen >= 65;
             const int nohp = v_evict ? (v_hp == 0 ? cap - 1 : v_hp - 1) : v_hp;
-            const uint32_t evmask = (uint32_t)ballot(v_evict);
             const uint32_t nA = v_moves ? ((uint32_t)nohp | ((uint32_t)nlen << 16)) : sA;
             const uint32_t nC = v_moves ? ((uint32_t)v_nh | ((uint32_t)v_nvel << 16) | ((uint32_t)nhp0 << SN_C_HP0_SHIFT)) : sC;
             hv = lane < NS ? nA : hv;
@@ -898,8 +907,12 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     if (ballot(((hitl >> (4 * s)) & 15u) != 0) != 0) hitmask |= 1u << s;
             }
             const uint32_t myhead = row_shl<8>(0u, hv) & 0xFFFFu;
-            const bool dead = lane < NS && ((hv >> 16) == 0 || !in_grid(myhead, dim) || ((hitmask >> lane) & 1u));
-            const uint32_t deadmask = (uint32_t)ballot(dead);
+            // (bitwise on purpose: `&&` / `||` here compile to nested exec-mask regions with branches)
+            const uint32_t hr = (myhead >> 8) - 1u, hc = (myhead & 255u) - 1u;  // head row / column in the grid, or >= dim
+            const uint32_t deadmask = (uint32_t)(ballot(lane < NS) &
+                                                 (ballot((hv >> 16) == 0) | ballot(hr >= (uint32_t)dim) | ballot(hc >= (uint32_t)dim) |
+                                                  ballot(((hitmask >> lane) & 1u) != 0)));
+            const bool dead = (deadmask >> lane) & 1u;
             if (RULES == MSNAKE_RULES_ADVERSARIAL && deadmask != 0) {
                 // [A]:183-186: every piece of a snake that dies this step (its out-of-grid head
                 // included) joins the fruit list, and spare_fruits grows by len per piece
