@@ -42,6 +42,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.basename(LIB_PATH).startswith("libmsnake"):
+        raise RuntimeError(f"MSNAKE_LIB={LIB_PATH}: only another build of libmsnake*.so may be named (kernel A/B runs)")
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: build the HIP extension first "
