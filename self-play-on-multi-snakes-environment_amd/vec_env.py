@@ -174,6 +174,32 @@ class MultiSnakeVecEnv:
                                         self._stream()), "msnake_step")
         return obs, self._rew, self._done, self._info
 
+    def rollout_device(self, tape, persistent=True, keep_obs=True):
+        """T lockstep steps from an action tape int32 cuda [T, num_envs, >= n_snakes] in ONE call.
+
+        persistent=True: msnake_rollout_tape (one launch, env state kept in registers across the steps);
+        False: msnake_step_tape (one launch per step, issued from C).  Same results either way, and the
+        same as T step_device() calls.  Returns fresh device tensors (obs uint8 [T, n, H, W, C] -- or
+        only the last step's [n, H, W, C] when keep_obs is False --, rew f32 [T, n], done u8 [T, n],
+        info i32 [T, n, 4]); nothing is synchronised."""
+        torch = self._torch
+        if tape.dtype != torch.int32 or tape.device != self.device or not tape.is_contiguous():
+            tape = tape.to(device=self.device, dtype=torch.int32).contiguous()
+        if tape.dim() != 3 or tape.shape[1] != self.num_envs or tape.shape[2] < self.n_snakes or tape.shape[0] < 1:
+            raise ValueError(f"tape must be [T >= 1, {self.num_envs}, >= {self.n_snakes}], got {tuple(tape.shape)}")
+        T, n = int(tape.shape[0]), self.num_envs
+        H, W, C = self.obs_shape
+        with torch.cuda.device(self.device):
+            obs = torch.empty(((T, n) if keep_obs else (n,)) + (H, W, C), dtype=torch.uint8, device=self.device)
+            rew = torch.empty((T, n), dtype=torch.float32, device=self.device)
+            done = torch.empty((T, n), dtype=torch.uint8, device=self.device)
+            info = torch.empty((T, n, 4), dtype=torch.int32, device=self.device)
+        fn = self._L.msnake_rollout_tape if persistent else self._L.msnake_step_tape
+        _capi.check(fn(self._h, tape.data_ptr(), int(tape.shape[2]), T, obs.data_ptr(), n * H * W * C if keep_obs else 0,
+                       rew.data_ptr(), done.data_ptr(), info.data_ptr(), n, self._stream()),
+                    "msnake_rollout_tape" if persistent else "msnake_step_tape")
+        return obs, rew, done, info
+
     def render_device(self, out=None):
         obs = self._out(out)
         _capi.check(self._L.msnake_render(self._h, obs.data_ptr(), self._stream()), "msnake_render")

@@ -745,3 +745,26 @@ def test_obs_alignment_is_checked_for_the_fused_upscale():
                             env._info.data_ptr(), env._stream())
     assert rc == -4 and b"aligned" in env._L.msnake_last_error()
     env.close()
+
+
+def test_rollout_device_wrapper_equals_single_steps():
+    """MultiSnakeVecEnv.rollout_device(): the Python face of msnake_rollout_tape / msnake_step_tape."""
+    import torch
+    n, T = 300, 20
+    envs = [_mk(num_envs=n, dim=19, n_snakes=3, rules="snake_env", seed=71) for _ in range(4)]
+    for e in envs:
+        e.reset()
+    tape = torch.randint(0, 5, (T, n, 3), dtype=torch.int32, device=envs[0].device)
+    ref = [tuple(x.clone() for x in envs[0].step_device(tape[t])) for t in range(T)]
+    o1, r1, d1, i1 = envs[1].rollout_device(tape)                      # persistent launch, all observations
+    o2, r2, d2, i2 = envs[2].rollout_device(tape, persistent=False)    # one launch per step
+    o3, r3, d3, i3 = envs[3].rollout_device(tape, keep_obs=False)      # only the last observation
+    for t in range(T):
+        for got in ((o1[t], r1[t], d1[t], i1[t]), (o2[t], r2[t], d2[t], i2[t])):
+            assert all(torch.equal(a, b) for a, b in zip(got, ref[t])), t
+        assert torch.equal(r3[t], ref[t][1]) and torch.equal(d3[t], ref[t][2]) and torch.equal(i3[t], ref[t][3]), t
+    assert torch.equal(o3, ref[-1][0])
+    with pytest.raises(ValueError, match="tape must be"):
+        envs[0].rollout_device(tape[:, :10])
+    for e in envs:
+        e.close()
