@@ -63,6 +63,20 @@ template <int N>
 __device__ __forceinline__ uint32_t row_shr(uint32_t old, uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x110 + N, 0xF, 0xF, false);
 }
+// v_mov_b32 dpp restricted to some rows (ROWS) and some groups of four lanes within each row (BANKS);
+// every other lane keeps `old`: a column of the env record is replaced by ONE instruction
+template <int CTRL, int ROWS, int BANKS>
+__device__ __forceinline__ uint32_t dpp_into(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWS, BANKS, false);
+}
+constexpr int DPP_IDENTITY = 0xE4;  // quad_perm:[0,1,2,3]
+// lane compares straight to a 64-bit lane mask (v_cmp into an SGPR pair), and a lane mask back to a
+// per-lane predicate without an instruction: `ballot(b)` of a bool that also has other uses costs a
+// v_cndmask + v_cmp pair, `(mask >> lane) & 1` a shift, an and and a compare
+constexpr int CMP_EQ = 32, CMP_NE = 33, CMP_UGE = 35, CMP_ULT = 36;
+template <int PRED>
+__device__ __forceinline__ uint64_t lanes_where(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, PRED); }
+__device__ __forceinline__ bool in_mask(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 // lane l <- lane l-1 (lane 0 keeps its value): v_mov_b32 dpp wave_shr:1
 __device__ __forceinline__ uint32_t shift_up1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false);
@@ -292,6 +306,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     uint32_t hv = hdr_g[short_rec ? (lane & (MSNAKE_HDR_SHORT_WORDS - 1)) : lane];
     hv = (short_rec && lane >= MSNAKE_HDR_SHORT_WORDS) ? 0u : hv;
     uint32_t cr[NS];            // cr[s], lane l: slot l of snake s's body ring; piece i sits in slot (hp0 + i) & 63
+    int pidx[NS];               // pidx[s], lane l: (l - hp0) & 63 = the piece in slot l (set by the collision test and by reset, for the painters)
 #pragma unroll
     for (int s = 0; s < NS; ++s) cr[s] = body0_g[s * 64 + lane];
     int actv = 0;
@@ -366,8 +381,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // ---- per-piece visitor: f(i, cell) for every piece i of snake s: the 64 most recent pieces from
     //      the body ring in registers (slot (hp0 + i) & 63), pieces >= 64 from the overflow ring ----
     //      wA / wC = the snake's SN_A / SN_C record words
-    auto for_each_piece = [&](int s, uint32_t reg, uint32_t wA, uint32_t wC, int s_len, auto&& f) {
-        const int i0 = (lane - (int)(wC >> SN_C_HP0_SHIFT)) & 63;
+    //      (for_each_piece_at: the caller already holds i0 = the piece index of this lane's ring slot)
+    auto for_each_piece_at = [&](int s, uint32_t reg, int i0, uint32_t wA, int s_len, auto&& f) {
         if (i0 < s_len) f(i0, reg);
         for (int base = 64; base < s_len; base += 64) {  // long bodies only
             const int i = base + lane;
@@ -377,6 +392,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 f(i, (uint32_t)__hip_atomic_load(&ring_of(s)[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
         }
+    };
+    auto for_each_piece = [&](int s, uint32_t reg, uint32_t wA, uint32_t wC, int s_len, auto&& f) {
+        for_each_piece_at(s, reg, (lane - (int)(wC >> SN_C_HP0_SHIFT)) & 63, wA, s_len, f);
     };
     // the 32-byte sector of snake s's body ring that holds slot `slot` goes back to memory (whole
     // sectors: nothing for the memory side to merge)
@@ -481,7 +499,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             for (int s = 0; s < NS; ++s) {
                 const uint32_t hd = rdlane(cellv, 4 * s), fc = rdlane(cellv, 4 * s + 2);
                 HV_SET(SN_C(s), hd);  // head cell, velocity (0,0), head in ring slot 0
-                cr[s] = hd;
+                cr[s] = hd; pidx[s] = lane;
                 store_ring_sector(s, hd, 0);
                 if (RULES == MSNAKE_RULES_ADVERSARIAL) {  // fruits = [] then append ([A]:224-229)
                     if (lane == s) { fr = fc; flist_of()[s] = (uint16_t)fc; }
@@ -502,7 +520,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 HV_SET(SN_A(s), 1u << 16);   // overflow empty, len 1
                 HV_SET(SN_B(s), 3u);         // grow_to 3
                 HV_SET(SN_C(s), hd);         // head cell, velocity (0,0), head in ring slot 0
-                cr[s] = hd;
+                cr[s] = hd; pidx[s] = lane;
                 store_ring_sector(s, hd, 0);
             }
         }
@@ -601,6 +619,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             reinterpret_cast<uint4*>(img)[k * 64 + lane] = reinterpret_cast<const uint4*>(bg)[k * 64 + lane];
     }
 
+    DBG_EXIT(7)
     if (STEPS) {
         LANE_FENCE();
         float reward = 0.0f;
@@ -608,40 +627,53 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         //         Valid whenever no moving snake eats (then no fruit respawns, so the updates do
         //         not depend on each other); otherwise the sequential loop below runs instead.
         constexpr int NF_STATIC = RULES == MSNAKE_RULES_NEW_WORLD ? -1 : NS;  // [S]: one fruit per snake
+        constexpr uint64_t NSMASK = (1ull << NS) - 1ull;                      // = ballot(lane < NS)
         const uint32_t sA = hv, sB = row_shl<4>(0u, hv), sC = row_shl<8>(0u, hv);
-        const int v_len = (int)(sA >> 16), v_hp = (int)(sA & 0xFFFFu), v_grow = (int)sB;
-        const int v_head = (int)(sC & 0xFFFFu), v_vel = (int)((sC >> 16) & 7u), v_hp0 = (int)((sC >> SN_C_HP0_SHIFT) & 63u);
-        // turn unless it is a 180-degree reversal: [S]:108-115 == [N]:34-41 == [A]:106-113
-        const int v_nvel = ((uint32_t)(actv - 1) < 4u && v_vel != ((actv + 1) & 3) + 1) ? actv : v_vel;
+        const int v_len = (int)(sA >> 16), v_grow = (int)sB;
+        const int v_head = (int)(sC & 0xFFFFu), v_vel = (int)((sC >> 16) & 7u);
+        // turn unless it is a 180-degree reversal: [S]:108-115 == [N]:34-41 == [A]:106-113.  Opposite
+        // directions are 1<->3 and 2<->4, i.e. (a - 1) ^ (vel - 1) == 2; no velocity yet (vel 0) never matches
+        const uint32_t am = (uint32_t)actv - 1u;
+        const bool turn = (am < 4u) & ((am ^ ((uint32_t)v_vel - 1u)) != 2u);
+        const int v_nvel = turn ? actv : v_vel;
+        // new head = head + step(vel): velocity 1..4 = (+1,0) (0,+1) (-1,0) (0,-1) on (row, column), 0 = none;
+        // both deltas come out of 2-bit signed fields of two constants (bit 2*vel)
+        const uint32_t vsh = (uint32_t)v_nvel << 1;
+        const int v_nh = v_head + __builtin_amdgcn_sbfe(0x310, vsh, 2u) + (__builtin_amdgcn_sbfe(0xC4, vsh, 2u) << 8);
         // snake_env moves only with a velocity ([S]:119); new_world always inserts a head, even a
         // duplicate of itself ([N]:43-48,153)
-        const bool v_moves = lane < NS && v_len > 0 && (RULES == MSNAKE_RULES_NEW_WORLD || v_nvel != 0);
-        int v_d = (v_nvel & 1) ? 256 : 1;
-        v_d = v_nvel >= 3 ? -v_d : v_d;
-        v_d = v_nvel == 0 ? 0 : v_d;
-        const int v_nh = v_head + v_d;
+        const uint64_t mvmask = NSMASK & lanes_where<CMP_NE>((uint32_t)v_len, 0u) &
+                                (RULES == MSNAKE_RULES_NEW_WORLD ? ~0ull : lanes_where<CMP_NE>((uint32_t)v_nvel, 0u));
+        const bool v_moves = in_mask(mvmask);
         uint32_t v_em = 0;  // bit f: fruit f lies on this snake's new head
-        if (RULES == MSNAKE_RULES_ADVERSARIAL) {
-            // list based, handled below
-        } else if (NF_STATIC >= 0) {
-#pragma unroll
-            for (int f = 0; f < (NF_STATIC >= 0 ? NF_STATIC : 0); ++f)
-                v_em |= ((uint32_t)v_nh == (rdlane(hv, FR0 + f) & 0xFFFFu)) ? (1u << f) : 0u;
-        } else {
-            for (int f = 0; f < nf; ++f)
-                v_em |= ((uint32_t)v_nh == (rdlane(hv, FR0 + f) & 0xFFFFu)) ? (1u << f) : 0u;
-        }
-        v_em = v_moves ? v_em : 0u;
+        bool any_eat = false;
         STAMP(1);
-        // (ballots of plain compares are the compares themselves; a ballot of a compound bool costs a
-        //  select and a second compare on top of the mask arithmetic)
-        const uint64_t mvmask = ballot(lane < NS) & ballot(v_len > 0) &
-                                (RULES == MSNAKE_RULES_NEW_WORLD ? ~0ull : ballot(v_nvel != 0));
-        bool any_eat = ballot(v_em != 0) != 0;
-        if (RULES == MSNAKE_RULES_ADVERSARIAL) {
+        if (RULES == MSNAKE_RULES_ADVERSARIAL) {  // list based
 #pragma unroll
             for (int s = 0; s < NS; ++s)
                 if (((mvmask >> s) & 1ull) && fruits_on(rdlane((uint32_t)v_nh, s)) != 0) any_eat = true;
+        } else if (RULES == MSNAKE_RULES_SNAKE_ENV) {
+            // fruit f is record word FR0 + f = lane FR0 + f: ONE compare per snake of every lane's low
+            // half against that snake's new head; the per-lane eat masks are only built when some bit is set
+            const uint32_t cellv = hv & 0xFFFFu;
+            uint32_t on = 0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const uint32_t m = (uint32_t)lanes_where<CMP_EQ>(cellv, rdlane((uint32_t)v_nh, s));
+                on |= ((mvmask >> s) & 1ull) ? m : 0u;
+            }
+            any_eat = (on & ((uint32_t)NSMASK << FR0)) != 0;
+            if (any_eat) {
+#pragma unroll
+                for (int f = 0; f < NS; ++f)
+                    v_em |= ((uint32_t)v_nh == (rdlane(hv, FR0 + f) & 0xFFFFu)) ? (1u << f) : 0u;
+                v_em = v_moves ? v_em : 0u;
+            }
+        } else {
+            for (int f = 0; f < nf; ++f)
+                v_em |= ((uint32_t)v_nh == (rdlane(hv, FR0 + f) & 0xFFFFu)) ? (1u << f) : 0u;
+            v_em = v_moves ? v_em : 0u;
+            any_eat = ballot(v_em != 0) != 0;
         }
         if (RULES == MSNAKE_RULES_SNAKE_ENV && any_eat) {
             // ---- 1a. [S] respawns, in snake order, ahead of the vector move.  update_snake
@@ -670,59 +702,55 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             }
             bf_moved = 0;
         }
-        if (RULES == MSNAKE_RULES_SNAKE_ENV || !any_eat) {
-            int pops;
+        // the vector update: valid whenever no moving snake eats -- and, for snake_env, after section 1a
+        const bool vec = RULES == MSNAKE_RULES_SNAKE_ENV || !any_eat;
+        if (vec) {
             uint32_t nB = (uint32_t)v_grow;
+            uint32_t nA;  // SN_A: overflow head position | length << 16
             if (RULES == MSNAKE_RULES_NEW_WORLD) {  // [N]:143-150 runs the pop test once per fruit
-                pops = v_len - v_grow + 1;
+                int pops = v_len - v_grow + 1;
                 pops = pops < 0 ? 0 : (pops > nf ? nf : pops);
-            } else if (RULES == MSNAKE_RULES_SNAKE_ENV) {
-                const int neat = __builtin_popcount(v_em);
-                nB = (uint32_t)(v_grow + 2 * neat);      // [S]:126-132
-                pops = v_len >= (int)nB ? 1 : 0;         // [S]:134-135
-                reward = (float)rdlane((uint32_t)neat, 0);
+                nA = sA + (v_moves ? ((uint32_t)(1 - pops) << 16) : 0u);  // insert(0, head) after the pops
             } else {
-                pops = v_len >= v_grow ? 1 : 0;     // [A]:134-135 (eating steps take the loop below)
+                if (RULES == MSNAKE_RULES_SNAKE_ENV && any_eat) {
+                    const int neat = __builtin_popcount(v_em);
+                    nB = (uint32_t)(v_grow + 2 * neat);      // [S]:126-132
+                    reward = (float)rdlane((uint32_t)neat, 0);
+                }
+                // [S]:134-135 / [A]:134-135 (eating steps of [A] take the loop below): the tail is popped iff
+                // len >= grow_to, then insert(0, head): the body grows by one exactly when len < grow_to
+                nA = sA + (in_mask(mvmask & lanes_where<CMP_ULT>((uint32_t)v_len, nB)) ? (1u << 16) : 0u);
             }
-            int nlen = v_len - pops + 1;            // insert(0, head)
             // bodies of 64+ cells (never under random play): capacity guard and eviction, behind ONE test
-            const uint64_t bigmask = ballot(nlen >= 64) & mvmask;
             uint32_t evmask = 0;
-            bool v_evict = false;
-            if (bigmask != 0) {
+            if ((mvmask & lanes_where<CMP_UGE>(nA, 64u << 16)) != 0) {
+                int nlen = (int)(nA >> 16);
                 if (ballot(v_moves && nlen > cap - 1) != 0) {  // unreachable under the documented caps
                     HV_SET_C(HDR_ACC_ERRORS, rdlane(hv, HDR_ACC_ERRORS) + 1u);
                     nlen = nlen > cap - 1 ? cap - 1 : nlen;
                 }
                 // the new head takes ring slot hp0 - 1, which held piece 63; if that piece stays part of the
                 // body (it becomes piece 64) it moves to the front of the overflow ring first
-                v_evict = v_moves && v_len >= 64 && nlen >= 65;
+                const bool v_evict = v_moves && v_len >= 64 && nlen >= 65;
                 evmask = (uint32_t)ballot(v_evict);
+                const int v_hp = (int)(sA & 0xFFFFu);
+                const int nohp = v_evict ? (v_hp == 0 ? cap - 1 : v_hp - 1) : v_hp;
+                nA = v_moves ? ((uint32_t)nohp | ((uint32_t)nlen << 16)) : sA;
             }
-            const int nhp0 = (v_hp0 - 1) & 63;
-            const int nohp = v_evict ? (v_hp == 0 ? cap - 1 : v_hp - 1) : v_hp;
-            const uint32_t nA = v_moves ? ((uint32_t)nohp | ((uint32_t)nlen << 16)) : sA;
-            const uint32_t nC = v_moves ? ((uint32_t)v_nh | ((uint32_t)v_nvel << 16) | ((uint32_t)nhp0 << SN_C_HP0_SHIFT)) : sC;
-            hv = lane < NS ? nA : hv;
-            if (RULES == MSNAKE_RULES_SNAKE_ENV) {
-                const uint32_t nB4 = row_shr<4>(hv, nB);
-                hv = (lane >= 4 && lane < 4 + NS) ? nB4 : hv;
-            }
-            const uint32_t nC8 = row_shr<8>(hv, nC);
-            hv = (lane >= 8 && lane < 8 + NS) ? nC8 : hv;
+            // SN_C: head | vel << 16 | ring slot of the head << 24, the slot steps down by one (mod 64)
+            const uint32_t nC = v_moves ? ((((sC - (1u << SN_C_HP0_SHIFT)) & (63u << SN_C_HP0_SHIFT)) | (uint32_t)v_nh) | ((uint32_t)v_nvel << 16)) : sC;
+            // the three columns go back into the record by one masked DPP move each (lanes s, 4+s, 8+s <- lane s;
+            // a lane without a moving snake carries its old words)
+            hv = dpp_into<DPP_IDENTITY, 0x1, 0x1>(hv, nA);
+            if (RULES == MSNAKE_RULES_SNAKE_ENV) hv = dpp_into<0x114, 0x1, 0x2>(hv, nB);
+            hv = dpp_into<0x118, 0x1, 0x4>(hv, nC);
             if (evmask != 0) {  // bodies of 64+ cells only
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
-                    if (((evmask >> s) & 1u) && lane == (int)rdlane((uint32_t)nhp0, s))
-                        ring_of(s)[rdlane((uint32_t)nohp, s)] = (uint16_t)cr[s];
+                    if (((evmask >> s) & 1u) && lane == (int)(rdlane(hv, SN_C(s)) >> SN_C_HP0_SHIFT))
+                        ring_of(s)[rdlane(hv, SN_A(s)) & 0xFFFFu] = (uint16_t)cr[s];
             }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {  // straight-line: a snake that does not move rewrites nothing
-                const int slot = (int)rdlane((uint32_t)nhp0, s);
-                const bool mv = (mvmask >> s) & 1ull;
-                cr[s] = (mv && lane == slot) ? rdlane((uint32_t)v_nh, s) : cr[s];
-                if (mv && ((lane ^ slot) < 16)) body0_g[s * 64 + lane] = (uint16_t)cr[s];
-            }
+            // (the new heads enter the body rings below, off the record words the collision test reads anyway)
         } else {
         // ---- 1b. sequential snake updates (order matters: a respawn sees earlier snakes moved,
         //          a later snake can eat a fruit respawned this very step) ----------------------
@@ -806,21 +834,33 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
         }
 
-        STAMP(2);
         LANE_FENCE();
-        DBG_EXIT(2)
-        // ---- 2. head-vs-piece matrix: some piece of snake j other than s's own head lies on
-        //         s's head.  [S] only needs "any j" per s; [N] needs the full matrix -------------
         uint32_t hd[NS], ln[NS], hp2[NS], wc[NS];  // head cell, length, overflow head pos, SN_C word
-        uint32_t maxlen = 0;
+        uint32_t maxw = 0;                         // largest SN_A word: some body is longer than 64 iff >= 65 << 16
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const uint32_t w0 = rdlane(hv, SN_A(s));
             wc[s] = rdlane(hv, SN_C(s));
             hd[s] = wc[s] & 0xFFFFu;
             ln[s] = w0 >> 16; hp2[s] = w0 & 0xFFFFu;
-            maxlen = ln[s] > maxlen ? ln[s] : maxlen;
+            maxw = w0 > maxw ? w0 : maxw;
         }
+        const bool longbody = maxw >= (65u << 16);
+        if (vec) {
+            // vector update, last part: each moving snake's new head enters its body ring at the slot SN_C
+            // names (one v_writelane), and the 32-byte sector around it goes back to memory
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if ((mvmask >> s) & 1ull) {  // straight-line: a snake that does not move rewrites nothing
+                    const uint32_t slot = wc[s] >> SN_C_HP0_SHIFT;
+                    cr[s] = hv_writelane(cr[s], hd[s], slot);
+                    if (((uint32_t)lane ^ slot) < 16u) body0_g[s * 64 + lane] = (uint16_t)cr[s];
+                }
+        }
+        STAMP(2);
+        DBG_EXIT(2)
+        // ---- 2. head-vs-piece matrix: some piece of snake j other than s's own head lies on
+        //         s's head.  [S] only needs "any j" per s; [N] needs the full matrix -------------
         uint32_t hitl = 0;      // [N]: per-lane accumulation, bit (4*s + j)
         uint64_t hit_s[NS];     // [S]/[A]: lanes whose cell lies on snake s's head (own head slot excluded)
 #pragma unroll
@@ -828,6 +868,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const uint32_t pi = (uint32_t)(lane - (int)(wc[j] >> SN_C_HP0_SHIFT)) & 63u;  // piece index of this slot
+            pidx[j] = (int)pi;  // (kept for the painters)
             const bool valid = pi < ln[j];
             if (RULES == MSNAKE_RULES_NEW_WORLD) {
 #pragma unroll
@@ -843,7 +884,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 }
             }
         }
-        if (maxlen > 64) {  // bodies longer than one chunk: the rest comes from the ring
+        if (longbody) {  // bodies longer than one chunk: the rest comes from the ring
 #pragma unroll
             for (int j = 0; j < NS; ++j)
                 for (int base = 64; base < (int)ln[j]; base += 64) {
@@ -897,22 +938,22 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             num_alive = NS - __builtin_popcount((flags >> 4) & 15u);
         } else {
             // [S]:147-164,178-197: simultaneous; lane s decides for snake s
-            uint32_t hitmask = 0;
+            uint32_t hitmask = 0;  // bit s = lane s: something lies on snake s's head
 #pragma unroll
             for (int s = 0; s < NS; ++s)
                 if (hit_s[s] != 0) hitmask |= 1u << s;
-            if (maxlen > 64) {  // overflow pieces were collected per lane
+            if (longbody) {  // overflow pieces were collected per lane
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
                     if (ballot(((hitl >> (4 * s)) & 15u) != 0) != 0) hitmask |= 1u << s;
             }
             const uint32_t myhead = row_shl<8>(0u, hv) & 0xFFFFu;
-            // (bitwise on purpose: `&&` / `||` here compile to nested exec-mask regions with branches)
+            // (lane masks on purpose: `&&` / `||` here compile to nested exec-mask regions with branches)
             const uint32_t hr = (myhead >> 8) - 1u, hc = (myhead & 255u) - 1u;  // head row / column in the grid, or >= dim
-            const uint32_t deadmask = (uint32_t)(ballot(lane < NS) &
-                                                 (ballot((hv >> 16) == 0) | ballot(hr >= (uint32_t)dim) | ballot(hc >= (uint32_t)dim) |
-                                                  ballot(((hitmask >> lane) & 1u) != 0)));
-            const bool dead = (deadmask >> lane) & 1u;
+            const uint32_t deadmask = (uint32_t)NSMASK &
+                                      ((uint32_t)lanes_where<CMP_ULT>(hv, 1u << 16) | (uint32_t)lanes_where<CMP_UGE>(hr, (uint32_t)dim) |
+                                       (uint32_t)lanes_where<CMP_UGE>(hc, (uint32_t)dim) | hitmask);
+            const bool dead = in_mask((uint64_t)deadmask);
             if (RULES == MSNAKE_RULES_ADVERSARIAL && deadmask != 0) {
                 // [A]:183-186: every piece of a snake that dies this step (its out-of-grid head
                 // included) joins the fruit list, and spare_fruits grows by len per piece
@@ -974,6 +1015,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         HV_SET_C(HDR_EP_RETURN, __float_as_uint(ep_ret));
         HV_SET_C(HDR_EP_LEN, ep_len);
         STAMP(4);
+        DBG_EXIT(5)
         STAMP_FLAG((unsigned long long)(any_eat ? 1 : 0) | (done ? 2ull : 0ull));
         if (lane == 0) {
             rew_t[e] = reward;
@@ -1022,7 +1064,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         for (int j = 0; j < NS; ++j) {
             const uint32_t w0 = rdlane(hv, SN_A(j));
             if (RULES == MSNAKE_RULES_NEW_WORLD && !((flags >> j) & 1u)) continue;  // [N]:219
-            for_each_piece(j, cr[j], w0, rdlane(hv, SN_C(j)), (int)(w0 >> 16), [&](int i, uint32_t cell) {
+            if (MODE == 2) pidx[j] = (lane - (int)(rdlane(hv, SN_C(j)) >> SN_C_HP0_SHIFT)) & 63;
+            for_each_piece_at(j, cr[j], pidx[j], w0, (int)(w0 >> 16), [&](int i, uint32_t cell) {
                 // Only a HEAD can lie outside the grid (msnake_set_state refuses anything else), and after
                 // a step or a reset no live snake's head does ([S]:147-164 / [N]:117-119 clear it): the
                 // clip against the wall ring is needed only when a freshly installed state is rendered.
@@ -1041,6 +1084,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
         wave_sync();
         STAMP(5);
+#ifdef MSNAKE_DBG_STAGES
+        if (dbg == 6) asm volatile("s_endpgm");  // (a `return` here trips the backend: illegal VGPR to SGPR copy)
+#endif
         if (K == 1) {
             // ---- 7. LDS image -> HBM: 16 bytes per lane, 1 KiB contiguous per wave instruction.
             //         The 3969-byte images are not 16-byte multiples, so the global side is

@@ -34,6 +34,15 @@ for rep in range(20):
             continue
         acc.setdefault(cls, []).append(np.stack([us[sel].min(0), np.median(us[sel], 0), us[sel].max(0)]))
         acc.setdefault(cls + "_n", []).append(sel.sum())
+dur = np.diff(us, axis=1)  # of the last repeat: per-wave time spent between consecutive stamps
+print("--- per-wave stage durations (last repeat): median / p90 / max us, and whole wave life")
+for i in range(6):
+    print(f"  {names[i]:>14s} -> {names[i + 1]:14s} {np.median(dur[:, i]):6.2f} {np.percentile(dur[:, i], 90):6.2f} {dur[:, i].max():6.2f}")
+life = us[:, 6] - us[:, 0]
+print(f"  wave life      median {np.median(life):.2f}  p90 {np.percentile(life, 90):.2f}  max {life.max():.2f};  last wave start {us[:, 0].max():.2f}, last stores issued {us[:, 6].max():.2f}")
+order = np.argsort(us[:, 0])
+late = order[-256:]
+print(f"  the 256 waves that start last: life median {np.median(life[late]):.2f}; stage medians " + " ".join(f"{np.median(dur[late, i]):.2f}" for i in range(6)))
 for cls in ("all", "fast", "eat", "done"):
     if cls not in acc:
         continue
