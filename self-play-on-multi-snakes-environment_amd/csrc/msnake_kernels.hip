@@ -311,7 +311,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     for (int s = 0; s < NS; ++s) cr[s] = body0_g[s * 64 + lane];
     int actv = 0;
     constexpr bool STEPS = MODE == 0 || MODE == 3;  // MODE 3: n_steps steps of an action tape in one launch
-    if (MODE == 0 && lane < NS) actv = actions[(uint32_t)e * (uint32_t)action_stride + (uint32_t)lane];
+    // (every lane loads -- lanes >= NS re-read the last snake's action, which nothing looks at -- instead of
+    //  an exec-mask region around three lanes)
+    if (MODE == 0) actv = actions[(uint32_t)e * (uint32_t)action_stride + (uint32_t)(lane < NS ? lane : NS - 1)];
     // adversarial rules keep a growing fruit LIST ([A]:183-185 appends dead bodies to it): entries
     // 0..63 in a VGPR like a body chunk (lane l = entry l), the complete list in HBM behind the rings
     const int fcap = (NS + NS * (n2 + 2) + 63) & ~63;
@@ -341,7 +343,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     uint32_t draws = 0, draw_base = 0, draws_n = 0;
     bool refilled = false;
     auto refill_draws = [&](uint32_t ctr_lo, uint32_t ctr_hi) {
-        const uint64_t gid = p.env_id_base + (uint64_t)e;
+        uint32_t ee = (uint32_t)e;
+        asm volatile("" : "+s"(ee));  // (slow path only, like the key schedule below)
+        const uint64_t gid = p.env_id_base + (uint64_t)ee;
         uint32_t k0 = p.seed_lo, k1 = p.seed_hi;
         // slow path only: keep the ten-round key schedule from being hoisted to kernel entry,
         // where it would pin 20 SGPRs for every wave
@@ -357,7 +361,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         if (PCACHE && !refilled && need <= HDR_PC_N && rdlane(hv, HDR_PC_VALID) == 1u) {
             const uint32_t pb = rdlane(hv, HDR_PC_BASE);
             if (ctr_lo - pb <= HDR_PC_N - need) {
-                draws = (uint32_t)__shfl((int)hv, lane + HDR_PC_FIRST);  // lane l <- record word 37 + l
+                int l2 = lane;
+                asm volatile("" : "+v"(l2));  // (keeps the lane arithmetic of this slow path out of the kernel's entry block)
+                draws = (uint32_t)__shfl((int)hv, l2 + HDR_PC_FIRST);  // lane l <- record word 37 + l
                 draw_base = pb; draws_n = HDR_PC_N;
                 return;
             }
@@ -590,17 +596,22 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         const int nk = img_bytes >> 10;
 #define MSNAKE_GP(k) ((const __attribute__((address_space(1))) void*)(tsrc + (k) * 64))
 #define MSNAKE_LP(k) ((__attribute__((address_space(3))) void*)(dst + (k) * 1024))
-        if (nk == 4) {  // the 21x21x9 image: one address pair, the instruction offset moves both sides
-            __builtin_amdgcn_global_load_lds(MSNAKE_GP(0), MSNAKE_LP(0), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(MSNAKE_GP(0), MSNAKE_LP(0), 16, 1024, 0);
-            __builtin_amdgcn_global_load_lds(MSNAKE_GP(0), MSNAKE_LP(0), 16, 2048, 0);
-            __builtin_amdgcn_global_load_lds(MSNAKE_GP(0), MSNAKE_LP(0), 16, 3072, 0);
-        } else if (nk == 2) {  // 12x12x9
-            __builtin_amdgcn_global_load_lds(MSNAKE_GP(0), MSNAKE_LP(0), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(MSNAKE_GP(0), MSNAKE_LP(0), 16, 1024, 0);
-        } else {
-            for (int k = 0; k < nk; ++k) __builtin_amdgcn_global_load_lds(MSNAKE_GP(k), MSNAKE_LP(k), 16, 0, 0);
-        }
+        // The first four KiB (the native images: 4 for 21x21x9, 2 for 12x12x9) go by ONE asm block: one M0
+        // write, one address pair (the instruction offset moves both sides), plain tests in between.  (The
+        // builtin re-writes M0 per load, and an if / else-if over nk becomes a flag-driven state machine.)
+        const uint32_t lds0 = (uint32_t)(uintptr_t)MSNAKE_LP(0);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, off\n\t"
+                     "s_cmp_lt_u32 %2, 2\n\ts_cbranch_scc1 1f\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:1024\n\t"
+                     "s_cmp_lt_u32 %2, 3\n\ts_cbranch_scc1 1f\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:2048\n\t"
+                     "s_cmp_lt_u32 %2, 4\n\ts_cbranch_scc1 1f\n\t"
+                     "global_load_lds_dwordx4 %0, off offset:3072\n"
+                     "1:"
+                     :: "v"(tsrc), "s"(uni(lds0)), "s"(uni((uint32_t)nk)) : "m0", "scc", "memory");
+        if (nk > 4)
+            for (int k = 4; k < nk; ++k) __builtin_amdgcn_global_load_lds(MSNAKE_GP(k), MSNAKE_LP(k), 16, 0, 0);
 #undef MSNAKE_GP
 #undef MSNAKE_LP
     }
@@ -608,6 +619,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // logic needs the state right away, and the painters must find the background in LDS.  In MODES
     // 0-2 no store has been issued yet, so this waits for loads only.
     if (!LDSBG || (step_i & 15) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the ring slots arrive zero-extended; hiding that they were 16-bit loads spares a v_and per snake)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(cr[s]));
     if (MODE == 3) {
         const int a = __shfl((int)abatch, 4 * (step_i & 15) + lane);
         actv = lane < NS ? a : 0;
@@ -656,12 +670,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             // fruit f is record word FR0 + f = lane FR0 + f: ONE compare per snake of every lane's low
             // half against that snake's new head; the per-lane eat masks are only built when some bit is set
             const uint32_t cellv = hv & 0xFFFFu;
+            const uint32_t nh_mv = v_moves ? (uint32_t)v_nh : 0xFFFFu;  // (no cell: a snake that stays eats nothing)
             uint32_t on = 0;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const uint32_t m = (uint32_t)lanes_where<CMP_EQ>(cellv, rdlane((uint32_t)v_nh, s));
-                on |= ((mvmask >> s) & 1ull) ? m : 0u;
-            }
+            for (int s = 0; s < NS; ++s) on |= (uint32_t)lanes_where<CMP_EQ>(cellv, rdlane(nh_mv, s));
             any_eat = (on & ((uint32_t)NSMASK << FR0)) != 0;
             if (any_eat) {
 #pragma unroll
@@ -1103,11 +1115,22 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             //  image, so that the edge cache lines two neighbouring images share meet in L2: WRITE_SIZE
             //  drops from 4 424 to 4 189 B per env at 262 144 envs, and the launch takes 387 instead of
             //  206-232 us -- mixing the two store kinds on one region is ruinous.  Rejected.)
+            // (the first four KiB unrolled: one address pair and instruction offsets instead of loop arithmetic)
+            const uint8_t* lsrc = img + 16 * lane;
+            uint8_t* gdst = obs_env + 16 * lane;
             if (pk2 & (MODE == 3 ? PK2_STREAM_TAPE : PK2_STREAM_OBS)) {  // streaming (nt) stores, see msnake_capi.hip: obs_store_policy
-                for (int k = lane; k < nfull; k += 64)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (lane < nfull - 64 * i)
+                        __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(lsrc + 1024 * i), reinterpret_cast<u32x4_unaligned*>(gdst + 1024 * i));
+                for (int k = lane + 256; k < nfull; k += 64)
                     __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(img)[k], reinterpret_cast<u32x4_unaligned*>(obs_env + 16 * k));
             } else {
-                for (int k = lane; k < nfull; k += 64)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (lane < nfull - 64 * i)
+                        *reinterpret_cast<uint4_unaligned*>(gdst + 1024 * i) = *reinterpret_cast<const uint4*>(lsrc + 1024 * i);
+                for (int k = lane + 256; k < nfull; k += 64)
                     *reinterpret_cast<uint4_unaligned*>(obs_env + 16 * k) = reinterpret_cast<const uint4*>(img)[k];
             }
             const int tail = (nfull << 4) + lane;
