@@ -77,6 +77,14 @@ constexpr int CMP_EQ = 32, CMP_NE = 33, CMP_UGE = 35, CMP_ULT = 36;
 template <int PRED>
 __device__ __forceinline__ uint64_t lanes_where(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, PRED); }
 __device__ __forceinline__ bool in_mask(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+// 1 << BIT if the (wave-uniform) lane mask is not empty, else 0: two scalar instructions.  (Written in C, a
+// uniform `m != 0` that is used as a number takes a detour through a VGPR.)
+template <int BIT>
+__device__ __forceinline__ uint32_t bit_if_any(uint64_t m) {
+    uint32_t b;
+    asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(b) : "s"(m), "n"(1u << BIT) : "scc");
+    return b;
+}
 // lane l <- lane l-1 (lane 0 keeps its value): v_mov_b32 dpp wave_shr:1
 __device__ __forceinline__ uint32_t shift_up1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false);
@@ -848,22 +856,24 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 
         LANE_FENCE();
         uint32_t hd[NS], ln[NS], hp2[NS], wc[NS];  // head cell, length, overflow head pos, SN_C word
-        uint32_t maxw = 0;                         // largest SN_A word: some body is longer than 64 iff >= 65 << 16
+        uint32_t lenor = 0;                        // OR of the SN_A words: some body holds 64+ cells iff >= 64 << 16
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const uint32_t w0 = rdlane(hv, SN_A(s));
             wc[s] = rdlane(hv, SN_C(s));
             hd[s] = wc[s] & 0xFFFFu;
             ln[s] = w0 >> 16; hp2[s] = w0 & 0xFFFFu;
-            maxw = w0 > maxw ? w0 : maxw;
+            lenor |= w0;
         }
-        const bool longbody = maxw >= (65u << 16);
+        const bool longbody = lenor >= (64u << 16);  // (gates the overflow-ring passes; a body of exactly 64 finds nothing there)
         if (vec) {
             // vector update, last part: each moving snake's new head enters its body ring at the slot SN_C
             // names (one v_writelane), and the 32-byte sector around it goes back to memory
+            uint32_t mv32 = (uint32_t)mvmask;
+            asm volatile("" : "+s"(mv32));  // (plain bit tests: known to be < 2^NS, bit NS-1 becomes a 64-bit VALU compare)
 #pragma unroll
             for (int s = 0; s < NS; ++s)
-                if ((mvmask >> s) & 1ull) {  // straight-line: a snake that does not move rewrites nothing
+                if ((mv32 >> s) & 1u) {  // straight-line: a snake that does not move rewrites nothing
                     const uint32_t slot = wc[s] >> SN_C_HP0_SHIFT;
                     cr[s] = hv_writelane(cr[s], hd[s], slot);
                     if (((uint32_t)lane ^ slot) < 16u) body0_g[s * 64 + lane] = (uint16_t)cr[s];
@@ -887,10 +897,11 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 for (int s = 0; s < NS; ++s)
                     hitl |= (valid && cr[j] == hd[s] && !(j == s && pi == 0)) ? (1u << (4 * s + j)) : 0u;
             } else {
-                const uint64_t vmask = ballot(valid);
+                // slots that hold no piece compare as "no cell": one select per snake instead of a mask AND per pair
+                const uint32_t crv = valid ? cr[j] : 0xFFFFFFFFu;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    uint64_t m = ballot(cr[j] == hd[s]) & vmask;
+                    uint64_t m = lanes_where<CMP_EQ>(crv, hd[s]);
                     if (j == s) m &= ~(1ull << (wc[j] >> SN_C_HP0_SHIFT));
                     hit_s[s] |= m;
                 }
@@ -913,7 +924,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
         DBG_EXIT(3)
         // ---- 3. aliveness, reward, done --------------------------------------------------------
-        bool done;
+        uint32_t done;  // 0 / 1, wave-uniform (an integer on the scalar unit, not a lane mask)
         int num_alive;
         const uint32_t t = rdlane(hv, HDR_T) + 1;
         if (RULES == MSNAKE_RULES_NEW_WORLD) {
@@ -946,14 +957,18 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             }
             HV_SET_C(HDR_FLAGS, flags);
             if (done0) reward = -1.0f;  // [NE]:39-40
-            done = (t >= max_steps) || done0;
+            done = ((t >= max_steps) || done0) ? 1u : 0u;
             num_alive = NS - __builtin_popcount((flags >> 4) & 15u);
         } else {
             // [S]:147-164,178-197: simultaneous; lane s decides for snake s
             uint32_t hitmask = 0;  // bit s = lane s: something lies on snake s's head
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                if (hit_s[s] != 0) hitmask |= 1u << s;
+            for (int s = 0; s < NS; ++s) {  // (j is a constant after unrolling)
+                if (s == 0) hitmask |= bit_if_any<0>(hit_s[s]);
+                else if (s == 1) hitmask |= bit_if_any<1>(hit_s[s]);
+                else if (s == 2) hitmask |= bit_if_any<2>(hit_s[s]);
+                else hitmask |= bit_if_any<3>(hit_s[s]);
+            }
             if (longbody) {  // overflow pieces were collected per lane
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
@@ -989,9 +1004,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 HV_SET_C(HDR_SPARE, (uint32_t)spare);
             }
             hv = dead ? (hv & 0xFFFFu) : hv;  // snakes[idx] = []
-            const bool main_dead = deadmask & 1u;
+            const uint32_t main_dead = deadmask & 1u;
             if (main_dead) reward = -1.0f;
-            done = (t >= max_steps) || main_dead;
+            done = main_dead | ((max_steps - 1u - t) >> 31);  // t >= max_steps (both below 2^16), without a predicate
             num_alive = NS - __builtin_popcount(deadmask);
         }
         HV_SET_C(HDR_T, t);
@@ -1005,6 +1020,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         uint32_t ep_len = rdlane(hv, HDR_EP_LEN) + 1;
         float out_ret = 0.0f;
         uint32_t out_len = 0;
+        done = uni(done);
+        asm volatile("" : "+s"(done));  // (keeps it one SGPR: as a predicate it becomes a lane mask, a select and a compare)
         if (done) {
             out_ret = ep_ret; out_len = ep_len;
             // logging totals stay in the env record (summed by msnake_get_stats): same-address
@@ -1031,10 +1048,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         STAMP_FLAG((unsigned long long)(any_eat ? 1 : 0) | (done ? 2ull : 0ull));
         if (lane == 0) {
             rew_t[e] = reward;
-            done_t[e] = done ? 1 : 0;
+            done_t[e] = (uint8_t)done;
             if (info_t) {
                 int4 iv;
-                iv.x = (int)__float_as_uint(out_ret); iv.y = (int)out_len; iv.z = num_alive; iv.w = done ? 1 : 0;
+                iv.x = (int)__float_as_uint(out_ret); iv.y = (int)out_len; iv.z = num_alive; iv.w = (int)done;
                 reinterpret_cast<int4*>(info_t)[e] = iv;
             }
         }
