@@ -278,7 +278,13 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // diagnostic build only: 100 MHz wall-clock stamps per wave, never read by the kernel itself
 #define STAMP(k) if (p.dbg_buf && lane == 0) p.dbg_buf[(size_t)e * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
 #define STAMP_FLAG(v) if (p.dbg_buf && lane == 0) p.dbg_buf[(size_t)e * 8 + 7] = (v)
+#define DBG_FEWER_STORES(i) && !((dbg & 0x200) && (i) > 0)  /* stage bit 9: timing with a quarter of the observation stores */
+#define DBG_NO_OBS_STORES(S) ((dbg & 0x400) ? 0 : (S))     /* bit 10: ... with none of them */
+#define DBG_NO_RECORD_STORE && !(dbg & 0x800)              /* bit 11: ... without the record write-back */
 #else
+#define DBG_FEWER_STORES(i)
+#define DBG_NO_OBS_STORES(S) (S)
+#define DBG_NO_RECORD_STORE
 #define DBG_EXIT(n)
 #define STAMP(k)
 #define STAMP_FLAG(v)
@@ -598,7 +604,11 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // M0 base + 16*l), so the copy holds no data VGPRs and needs no ds_write.
     // (Issuing it only after the state has arrived, so that no wave's state load queues behind
     //  another wave's 4 KB of background, was measured too: 6.88 instead of 6.79 us, same box.)
+#ifdef MSNAKE_DBG_STAGES
+    if (obs_t && (!LDSBG || step_i == 0) && !(dbg & 0x100)) {  // (stage bit 8: timing without the background DMA -- wrong images)
+#else
     if (obs_t && (!LDSBG || step_i == 0)) {
+#endif
         const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl_of()) + lane;
         uint8_t* dst = LDSBG ? bg : img;
         const int nk = img_bytes >> 10;
@@ -1122,7 +1132,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             //         byte-aligned (the hardware splits the few lines that straddle); the last
             //         S%16 bytes go singly.
             uint8_t* obs_env = obs_t + (size_t)e * S;
-            const int nfull = S >> 4;
+            const int nfull = DBG_NO_OBS_STORES(S) >> 4;
             // One LDS read -> one store per KiB, in a plain loop.  (Measured and rejected, same box:
             // all LDS reads first and then the stores back to back -- fewer instructions, but 7.65
             // instead of 6.9 us per launch at 4 096 envs: a wave's burst of stores sits in its CU's
@@ -1132,13 +1142,17 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             //  image, so that the edge cache lines two neighbouring images share meet in L2: WRITE_SIZE
             //  drops from 4 424 to 4 189 B per env at 262 144 envs, and the launch takes 387 instead of
             //  206-232 us -- mixing the two store kinds on one region is ruinous.  Rejected.)
+            // (Round 2, same box each: the LDS read of KiB i+1 in flight while KiB i is stored -- 6.52-6.58 vs
+            //  6.52-6.58 us, no change; other cache policies for the 16-byte stores than `nt`: sc1 6.2-6.5,
+            //  sc0 sc1 6.1-6.4, sc0 7.0, nt sc1 8.3, plain 7.6 against 5.91 us for `nt`.  A quarter of the stores
+            //  takes as long as all of them (diagnostic build, stage bit 9): the tail is their latency.)
             // (the first four KiB unrolled: one address pair and instruction offsets instead of loop arithmetic)
             const uint8_t* lsrc = img + 16 * lane;
             uint8_t* gdst = obs_env + 16 * lane;
             if (pk2 & (MODE == 3 ? PK2_STREAM_TAPE : PK2_STREAM_OBS)) {  // streaming (nt) stores, see msnake_capi.hip: obs_store_policy
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (lane < nfull - 64 * i)
+                    if (lane < nfull - 64 * i DBG_FEWER_STORES(i))
                         __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(lsrc + 1024 * i), reinterpret_cast<u32x4_unaligned*>(gdst + 1024 * i));
                 for (int k = lane + 256; k < nfull; k += 64)
                     __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(img)[k], reinterpret_cast<u32x4_unaligned*>(obs_env + 16 * k));
@@ -1151,7 +1165,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     *reinterpret_cast<uint4_unaligned*>(obs_env + 16 * k) = reinterpret_cast<const uint4*>(img)[k];
             }
             const int tail = (nfull << 4) + lane;
-            if (tail < S) obs_env[tail] = img[tail];
+            if (tail < DBG_NO_OBS_STORES(S)) obs_env[tail] = img[tail];
         } else {
             // ---- 7'. fused WarpFrame: the LDS image is already K-fold wide; every row of it is
             //          stored to K consecutive output rows.  Rows are W*K*C bytes = a whole number of
@@ -1195,7 +1209,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 HV_SET_C(HDR_PC_VALID, 0u);
             }
         }
-        if (!short_rec || lane < MSNAKE_HDR_SHORT_WORDS) {
+        if ((!short_rec || lane < MSNAKE_HDR_SHORT_WORDS) DBG_NO_RECORD_STORE) {
             uint32_t ee = (uint32_t)e;
             if (MODE == 3) asm volatile("" : "+s"(ee));  // (the pointer is not held across the step loop)
             (reinterpret_cast<uint32_t*>(state) + (size_t)ee * MSNAKE_HDR_WORDS)[lane] = hv;
