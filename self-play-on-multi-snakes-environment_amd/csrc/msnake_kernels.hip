@@ -674,16 +674,16 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         const int v_nh = v_head + __builtin_amdgcn_sbfe(0x310, vsh, 2u) + (__builtin_amdgcn_sbfe(0xC4, vsh, 2u) << 8);
         // snake_env moves only with a velocity ([S]:119); new_world always inserts a head, even a
         // duplicate of itself ([N]:43-48,153)
-        const uint64_t mvmask = NSMASK & lanes_where<CMP_NE>((uint32_t)v_len, 0u) &
-                                (RULES == MSNAKE_RULES_NEW_WORLD ? ~0ull : lanes_where<CMP_NE>((uint32_t)v_nvel, 0u));
-        const bool v_moves = in_mask(mvmask);
+        const uint32_t mvmask = (uint32_t)NSMASK & (uint32_t)lanes_where<CMP_NE>((uint32_t)v_len, 0u) &
+                                (RULES == MSNAKE_RULES_NEW_WORLD ? ~0u : (uint32_t)lanes_where<CMP_NE>((uint32_t)v_nvel, 0u));
+        const bool v_moves = in_mask((uint64_t)mvmask);
         uint32_t v_em = 0;  // bit f: fruit f lies on this snake's new head
         bool any_eat = false;
         STAMP(1);
         if (RULES == MSNAKE_RULES_ADVERSARIAL) {  // list based
 #pragma unroll
             for (int s = 0; s < NS; ++s)
-                if (((mvmask >> s) & 1ull) && fruits_on(rdlane((uint32_t)v_nh, s)) != 0) any_eat = true;
+                if (((mvmask >> s) & 1u) && fruits_on(rdlane((uint32_t)v_nh, s)) != 0) any_eat = true;
         } else if (RULES == MSNAKE_RULES_SNAKE_ENV) {
             // fruit f is record word FR0 + f = lane FR0 + f: ONE compare per snake of every lane's low
             // half against that snake's new head; the per-lane eat masks are only built when some bit is set
@@ -749,11 +749,11 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 }
                 // [S]:134-135 / [A]:134-135 (eating steps of [A] take the loop below): the tail is popped iff
                 // len >= grow_to, then insert(0, head): the body grows by one exactly when len < grow_to
-                nA = sA + (in_mask(mvmask & lanes_where<CMP_ULT>((uint32_t)v_len, nB)) ? (1u << 16) : 0u);
+                nA = sA + (in_mask((uint64_t)(mvmask & (uint32_t)lanes_where<CMP_ULT>((uint32_t)v_len, nB))) ? (1u << 16) : 0u);
             }
             // bodies of 64+ cells (never under random play): capacity guard and eviction, behind ONE test
             uint32_t evmask = 0;
-            if ((mvmask & lanes_where<CMP_UGE>(nA, 64u << 16)) != 0) {
+            if ((mvmask & (uint32_t)lanes_where<CMP_UGE>(nA, 64u << 16)) != 0) {
                 int nlen = (int)(nA >> 16);
                 if (ballot(v_moves && nlen > cap - 1) != 0) {  // unreachable under the documented caps
                     HV_SET_C(HDR_ACC_ERRORS, rdlane(hv, HDR_ACC_ERRORS) + 1u);
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         if (vec) {
             // vector update, last part: each moving snake's new head enters its body ring at the slot SN_C
             // names (one v_writelane), and the 32-byte sector around it goes back to memory
-            uint32_t mv32 = (uint32_t)mvmask;
+            uint32_t mv32 = mvmask;
             asm volatile("" : "+s"(mv32));  // (plain bit tests: known to be < 2^NS, bit NS-1 becomes a 64-bit VALU compare)
 #pragma unroll
             for (int s = 0; s < NS; ++s)
