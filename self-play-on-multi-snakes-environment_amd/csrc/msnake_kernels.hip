@@ -7,11 +7,14 @@
 //     addresses that depend only on the env index, so they are issued together at kernel entry.
 //     Only bodies longer than 64 cells touch their overflow ring (dependent loads, rare).
 //   * the env record stays in ONE VGPR for the whole kernel: scalar game logic reads fields with
-//     v_readlane and writes them back by lane select, so almost nothing is live in SGPRs; the three
+//     v_readlane and writes them back with v_writelane, so almost nothing is live in SGPRs; the three
 //     per-snake columns of the record (lane s = snake s after a DPP row shift) let all snakes turn,
-//     move, eat and grow at once on the VALU;
-//   * body pieces are lane-distributed: a move overwrites ONE ring slot (the new head), collisions
-//     are compares + ballots (head-vs-piece matrix), fruit eating is a compare against the fruit lanes;
+//     move, eat and grow at once on the VALU, and go back by one row/bank-masked DPP move each;
+//   * per-lane decisions are lane masks: compares write SGPR pairs directly (llvm.amdgcn.icmp), the
+//     mask arithmetic runs on the scalar unit, a mask becomes a predicate again for free (inverse ballot);
+//   * body pieces are lane-distributed: a move overwrites ONE ring slot (the new head, v_writelane),
+//     collisions are compares into lane masks (head-vs-piece matrix), fruit eating is one compare per
+//     snake of the fruit lanes against its new head;
 //   * fruit respawn (slow path): one occupancy BIT per cell in LDS (ds_or) -> lane c owns the 64
 //     cells of chunk c as a register mask -> DPP prefix sum of the per-lane free counts -> k-th free
 //     cell; Philox4x32-10 on the VALU, lane l computing draw ctr + l (one evaluation = 64 draws);
