@@ -359,6 +359,11 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     constexpr bool PCACHE = RULES != MSNAKE_RULES_NEW_WORLD;  // new_world's fruits may fill the record
     uint32_t draws = 0, draw_base = 0, draws_n = 0;
     bool refilled = false;
+    // words 32..63 of a snake_env record only hold the Philox cache: they go back to memory in the launches
+    // that change it (a Philox evaluation, the 2^32-draw wrap), not in every one.  (new_world keeps its fruits
+    // there; the adversarial kernels have no SGPR to spare for the flag.)
+    constexpr bool UPPER_TRACKED = RULES == MSNAKE_RULES_SNAKE_ENV;
+    bool upper_dirty = !UPPER_TRACKED;
     auto refill_draws = [&](uint32_t ctr_lo, uint32_t ctr_hi) {
         uint32_t ee = (uint32_t)e;
         asm volatile("" : "+s"(ee));  // (slow path only, like the key schedule below)
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     auto ctr_wrapped = [&](uint32_t ctr_hi) {  // once per 2^32 draws: drop both caches
         HV_SET_C(HDR_CTR_HI, ctr_hi + 1);
         draws_n = 0;
-        if (PCACHE) HV_SET_C(HDR_PC_VALID, 0u);
+        if (PCACHE) { HV_SET_C(HDR_PC_VALID, 0u); if (UPPER_TRACKED) upper_dirty = true; }
     };
     auto randint = [&](uint32_t n) -> uint32_t {  // ensure_draws() has covered this draw
         const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
@@ -1201,6 +1206,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     if (MODE != 2) {
         if (PCACHE && refilled && !short_rec) {
             // Philox ran in this launch: its unused draws go into the record for the launches to come
+            if (UPPER_TRACKED) upper_dirty = true;
             const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO);
             const uint32_t off = ctr_lo - draw_base;
             if (draws_n == 64 && off + HDR_PC_N <= 64u) {
@@ -1212,7 +1218,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 HV_SET_C(HDR_PC_VALID, 0u);
             }
         }
-        if ((!short_rec || lane < MSNAKE_HDR_SHORT_WORDS) DBG_NO_RECORD_STORE) {
+        if ((lane < MSNAKE_HDR_SHORT_WORDS || (!short_rec && upper_dirty)) DBG_NO_RECORD_STORE) {
             uint32_t ee = (uint32_t)e;
             if (MODE == 3) asm volatile("" : "+s"(ee));  // (the pointer is not held across the step loop)
             (reinterpret_cast<uint32_t*>(state) + (size_t)ee * MSNAKE_HDR_WORDS)[lane] = hv;
