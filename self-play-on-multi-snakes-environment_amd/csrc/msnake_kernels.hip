@@ -277,17 +277,17 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     unpack();
 #ifdef MSNAKE_DBG_STAGES
     const uint32_t dbg = p.dbg_stage;  // timing-only early exits
-#define DBG_EXIT(n) if (dbg == (n)) { if (hv == 0xDEADBEEFu) hdr_g[lane] = hv + cr[0] + (uint32_t)actv; return; }
+// (s_endpgm rather than `return`: an early return from the middle of this kernel trips the backend --
+//  "illegal VGPR to SGPR copy" -- once a wave-uniform bool is live across it)
+#define DBG_EXIT(n) if (dbg == (n)) { if (hv == 0xDEADBEEFu) hdr_g[lane] = hv + cr[0] + (uint32_t)actv; asm volatile("s_endpgm"); }
     // diagnostic build only: 100 MHz wall-clock stamps per wave, never read by the kernel itself
 #define STAMP(k) if (p.dbg_buf && lane == 0) p.dbg_buf[(size_t)e * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
 #define STAMP_FLAG(v) if (p.dbg_buf && lane == 0) p.dbg_buf[(size_t)e * 8 + 7] = (v)
 #define DBG_FEWER_STORES(i) && !((dbg & 0x200) && (i) > 0)  /* stage bit 9: timing with a quarter of the observation stores */
 #define DBG_NO_OBS_STORES(S) ((dbg & 0x400) ? 0 : (S))     /* bit 10: ... with none of them */
-#define DBG_NO_RECORD_STORE && !(dbg & 0x800)              /* bit 11: ... without the record write-back */
 #else
 #define DBG_FEWER_STORES(i)
 #define DBG_NO_OBS_STORES(S) (S)
-#define DBG_NO_RECORD_STORE
 #define DBG_EXIT(n)
 #define STAMP(k)
 #define STAMP_FLAG(v)
@@ -503,7 +503,14 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             const uint64_t sel = ballot(((m >> lane) & 1ull) && mbcnt(m) == kk);
             x = L * 64 + (__builtin_ffsll((long long)sel) - 1);
         }
-        return (uint32_t)(((x % dim + 1) << 8) | (x / dim + 1));
+        // x / dim and x % dim without a division: pk2 carries M = floor(2^k / dim) + 1 with k = 14 + bits(dim),
+        // exact for every x < 2^14 (cell indices stay below 63^2); the launch glue computes M
+        uint32_t p2 = pk2v;
+        asm volatile("" : "+s"(p2));  // (slow path only: nothing of this belongs in the entry block)
+        const uint32_t sh = 14u + 32u - (uint32_t)__builtin_clz((uint32_t)dim);
+        const uint32_t q = ((uint32_t)x * (p2 >> PK2_DIVM_SHIFT)) >> sh;
+        const uint32_t r = (uint32_t)x - q * (uint32_t)dim;
+        return ((r + 1u) << 8) | (q + 1u);
     };
 
     // ---- reset: [S]:219-232 / [NE]:27-33 -> [N]:55-73 ------------------------------------------
@@ -585,6 +592,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     if (MODE == 3) {
         asm volatile("" : "+v"(lane), "+s"(pk0v), "+s"(pk1v), "+s"(pk2v));
         unpack();
+        __builtin_amdgcn_s_setprio(0);  // (a slow path of the previous step raised it)
     }
     // MODE 3 issues NO vector-memory load in a normal step: gfx9 has one counter for loads and
     // stores, so waiting for a load would also wait for every observation store still in flight
@@ -714,6 +722,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             any_eat = ballot(v_em != 0) != 0;
         }
         if (RULES == MSNAKE_RULES_SNAKE_ENV && any_eat) {
+            // A wave on a slow path (respawn, reset) is the one the launch will wait for: it gets the issue
+            // slots of its SIMD first from here on.  (Same box, median of six: 5.74 vs 5.87 us per launch.)
+            __builtin_amdgcn_s_setprio(3);
             // ---- 1a. [S] respawns, in snake order, ahead of the vector move.  update_snake
             //      ([S]:119-141) pops, inserts the head and only then re-places the fruits it ate, so
             //      snake s's respawns see snakes <= s moved and snakes > s unmoved; a fruit that lands
@@ -792,6 +803,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         } else {
         // ---- 1b. sequential snake updates (order matters: a respawn sees earlier snakes moved,
         //          a later snake can eat a fruit respawned this very step) ----------------------
+        __builtin_amdgcn_s_setprio(3);
 #pragma nounroll
         for (int s = 0; s < NS; ++s) {  // a real loop: the slow path below exists once in the code
             LANE_FENCE();
@@ -1056,6 +1068,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             }
             if (auto_reset) {
                 ep_ret = 0.0f; ep_len = 0;
+                __builtin_amdgcn_s_setprio(3);
                 do_reset();
             }
         }
@@ -1078,6 +1091,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // ---- 6. paint the observation over the background, in reference order ----------------------
     LANE_FENCE();
     if (obs_t) {
+#ifdef MSNAKE_PRIO_PAINT
+        __builtin_amdgcn_s_setprio(MSNAKE_PRIO_PAINT);
+#endif
         wave_sync();
         uint8_t* px = img;
         // fruits first ([S]:43-44): red in every view; the background is already black
@@ -1132,7 +1148,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         wave_sync();
         STAMP(5);
 #ifdef MSNAKE_DBG_STAGES
-        if (dbg == 6) asm volatile("s_endpgm");  // (a `return` here trips the backend: illegal VGPR to SGPR copy)
+        if (dbg == 6) asm volatile("s_endpgm");
 #endif
         if (K == 1) {
             // ---- 7. LDS image -> HBM: 16 bytes per lane, 1 KiB contiguous per wave instruction.
@@ -1218,7 +1234,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 HV_SET_C(HDR_PC_VALID, 0u);
             }
         }
-        if ((lane < MSNAKE_HDR_SHORT_WORDS || (!short_rec && upper_dirty)) DBG_NO_RECORD_STORE) {
+        if ((lane < MSNAKE_HDR_SHORT_WORDS || (!short_rec && upper_dirty))) {
             uint32_t ee = (uint32_t)e;
             if (MODE == 3) asm volatile("" : "+s"(ee));  // (the pointer is not held across the step loop)
             (reinterpret_cast<uint32_t*>(state) + (size_t)ee * MSNAKE_HDR_WORDS)[lane] = hv;
@@ -1458,6 +1474,13 @@ hipError_t launch_state_unpack(const StepParams& p, int rules, int env0, int cou
 // ------------------------------------------------------------------------------------------------
 // launch glue (called from the C-ABI in msnake_capi.hip)
 // ------------------------------------------------------------------------------------------------
+// M of the kernel's division-free x / dim (safe_cell): floor(2^(14 + bits(dim)) / dim) + 1 <= 2^15 + 1
+static uint32_t div_magic(uint32_t dim) {
+    uint32_t bits = 0;
+    while ((dim >> bits) != 0) ++bits;
+    return (uint32_t)((1ull << (14u + bits)) / dim) + 1u;
+}
+
 template <int RULES, int NS, int K>
 static hipError_t launch_k(const StepParams& p, int mode, int epb, hipStream_t stream) {
     const uint32_t pk0 = (uint32_t)p.dim | ((uint32_t)p.n_fruits << 6) | ((uint32_t)p.action_stride << 12) |
@@ -1472,8 +1495,8 @@ static hipError_t launch_k(const StepParams& p, int mode, int epb, hipStream_t s
     }
     const size_t lds = lds_wave * (size_t)epb;
     const uint32_t pk2 = (p.short_rec ? PK2_SHORT_REC : 0u) | (p.rest.stream_obs ? PK2_STREAM_OBS : 0u) |
-                         (p.stream_tape ? PK2_STREAM_TAPE : 0u) | 
-                         ((uint32_t)epb << PK2_EPB_SHIFT);
+                         (p.stream_tape ? PK2_STREAM_TAPE : 0u) | ((uint32_t)epb << PK2_EPB_SHIFT) |
+                         (div_magic((uint32_t)p.dim) << PK2_DIVM_SHIFT);
     const dim3 grid((unsigned)((p.nenv + epb - 1) / epb));
     const dim3 block(64u * (unsigned)epb);
 #define MSNAKE_LAUNCH(M)                                                                                       \
