@@ -161,6 +161,16 @@ __device__ __forceinline__ uint32_t hv_writelane(uint32_t old, uint32_t val, uin
 }
 #define HV_SET_C(idx, val) hv = hv_writelane_c<(idx)>(hv, (uint32_t)(val))
 #define HV_SET(idx, val) hv = hv_writelane(hv, (uint32_t)(val), (uint32_t)(idx))
+// index that is a constant once the enclosing loop is unrolled (snake columns, inline fruits): the switch
+// folds to the immediate form -- one instruction instead of M0 write + hazard nop + v_writelane.
+// Never for an index that is only known at run time (that would be a 32-way jump table).
+__device__ __forceinline__ uint32_t hv_writelane_unrolled(uint32_t old, uint32_t val, uint32_t idx) {
+    switch (idx) {
+        case 0: return hv_writelane_c<0>(old, val); case 1: return hv_writelane_c<1>(old, val); case 2: return hv_writelane_c<2>(old, val); case 3: return hv_writelane_c<3>(old, val); case 4: return hv_writelane_c<4>(old, val); case 5: return hv_writelane_c<5>(old, val); case 6: return hv_writelane_c<6>(old, val); case 7: return hv_writelane_c<7>(old, val); case 8: return hv_writelane_c<8>(old, val); case 9: return hv_writelane_c<9>(old, val); case 10: return hv_writelane_c<10>(old, val); case 11: return hv_writelane_c<11>(old, val); case 12: return hv_writelane_c<12>(old, val); case 13: return hv_writelane_c<13>(old, val); case 14: return hv_writelane_c<14>(old, val); case 15: return hv_writelane_c<15>(old, val); case 16: return hv_writelane_c<16>(old, val); case 17: return hv_writelane_c<17>(old, val); case 18: return hv_writelane_c<18>(old, val); case 19: return hv_writelane_c<19>(old, val); case 20: return hv_writelane_c<20>(old, val); case 21: return hv_writelane_c<21>(old, val); case 22: return hv_writelane_c<22>(old, val); case 23: return hv_writelane_c<23>(old, val); case 24: return hv_writelane_c<24>(old, val); case 25: return hv_writelane_c<25>(old, val); case 26: return hv_writelane_c<26>(old, val); case 27: return hv_writelane_c<27>(old, val); case 28: return hv_writelane_c<28>(old, val); case 29: return hv_writelane_c<29>(old, val); case 30: return hv_writelane_c<30>(old, val); case 31: return hv_writelane_c<31>(old, val);
+        default: return hv_writelane(old, val, idx);
+    }
+}
+#define HV_SET_U(idx, val) hv = hv_writelane_unrolled(hv, (uint32_t)(val), (uint32_t)(idx))
 #define HV_SET_DYN(idx, val) HV_SET(idx, val)
 
 typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     auto do_reset = [&]() {
         if (RULES == MSNAKE_RULES_NEW_WORLD) {  // bodies must be empty while the first ones are placed
 #pragma unroll
-            for (int s = 0; s < NS; ++s) HV_SET(SN_A(s), 0u);
+            for (int s = 0; s < NS; ++s) HV_SET_U(SN_A(s), 0u);
         }
         if (RULES != MSNAKE_RULES_NEW_WORLD) {
             // [S]:223-225 draws snake s's cell then fruit s's cell, each (randint(dim), randint(dim)):
@@ -533,14 +543,14 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const uint32_t hd = rdlane(cellv, 4 * s), fc = rdlane(cellv, 4 * s + 2);
-                HV_SET(SN_C(s), hd);  // head cell, velocity (0,0), head in ring slot 0
+                HV_SET_U(SN_C(s), hd);  // head cell, velocity (0,0), head in ring slot 0
                 cr[s] = hd; pidx[s] = lane;
                 store_ring_sector(s, hd, 0);
                 if (RULES == MSNAKE_RULES_ADVERSARIAL) {  // fruits = [] then append ([A]:224-229)
                     if (lane == s) { fr = fc; flist_of()[s] = (uint16_t)fc; }
                     fr_dirty = true;
                 } else {
-                    HV_SET(FR0 + s, fc);
+                    HV_SET_U(FR0 + s, fc);
                 }
             }
             const uint32_t nlo = ctr_lo + 4u * NS;
@@ -552,9 +562,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             for (int s = 0; s < NS; ++s) {
                 const uint32_t c0 = randint((uint32_t)dim), c1 = randint((uint32_t)dim);
                 const uint32_t hd = ((c0 + 1) << 8) | (c1 + 1);
-                HV_SET(SN_A(s), 1u << 16);   // overflow empty, len 1
-                HV_SET(SN_B(s), 3u);         // grow_to 3
-                HV_SET(SN_C(s), hd);         // head cell, velocity (0,0), head in ring slot 0
+                HV_SET_U(SN_A(s), 1u << 16);   // overflow empty, len 1
+                HV_SET_U(SN_B(s), 3u);         // grow_to 3
+                HV_SET_U(SN_C(s), hd);         // head cell, velocity (0,0), head in ring slot 0
                 cr[s] = hd; pidx[s] = lane;
                 store_ring_sector(s, hd, 0);
             }
@@ -721,6 +731,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             v_em = v_moves ? v_em : 0u;
             any_eat = ballot(v_em != 0) != 0;
         }
+#ifdef MSNAKE_DBG_STAGES
+        if (dbg & 0x1000) any_eat = false;  // stage bit 12: timing with every wave on the fast path (wrong results)
+#endif
         if (RULES == MSNAKE_RULES_SNAKE_ENV && any_eat) {
             // A wave on a slow path (respawn, reset) is the one the launch will wait for: it gets the issue
             // slots of its SIMD first from here on.  (Same box, median of six: 5.74 vs 5.87 us per launch.)
@@ -980,7 +993,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     if (other) { ln[s] = 0; alive = false; }
                     else alive = !((hits >> (4 * s + s)) & 1u);  // self hit: not alive, body kept
                 }
-                if (ln[s] == 0) HV_SET(SN_A(s), hp2[s]);
+                if (ln[s] == 0) HV_SET_U(SN_A(s), hp2[s]);
                 flags = alive ? (flags | (1u << s)) : (flags & ~(1u << s));
                 if (!alive) flags |= (16u << s);  // dead_snakes, append-once
                 if (s == 0) done0 = alive;        // [N]:107 (sic)
@@ -1051,6 +1064,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         float out_ret = 0.0f;
         uint32_t out_len = 0;
         done = uni(done);
+#ifdef MSNAKE_DBG_STAGES
+        if (dbg & 0x1000) done = 0;
+#endif
         asm volatile("" : "+s"(done));  // (keeps it one SGPR: as a predicate it becomes a lane mask, a select and a compare)
         if (done) {
             out_ret = ep_ret; out_len = ep_len;
