@@ -293,12 +293,15 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // diagnostic build only: 100 MHz wall-clock stamps per wave, never read by the kernel itself
 #define STAMP(k) if (p.dbg_buf && lane == 0) p.dbg_buf[(size_t)e * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
 #define STAMP_FLAG(v) if (p.dbg_buf && lane == 0) p.dbg_buf[(size_t)e * 8 + 7] = (v)
+// second row of stamps per env (rows nenv .. 2*nenv-1 of the buffer): inside the respawn path
+#define STAMP2(k) if (p.dbg_buf && lane == 0) p.dbg_buf[((size_t)nenv + (size_t)e) * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
 #define DBG_FEWER_STORES(i) && !((dbg & 0x200) && (i) > 0)  /* stage bit 9: timing with a quarter of the observation stores */
 #define DBG_NO_OBS_STORES(S) ((dbg & 0x400) ? 0 : (S))     /* bit 10: ... with none of them */
 #else
 #define DBG_FEWER_STORES(i)
 #define DBG_NO_OBS_STORES(S) (S)
 #define DBG_EXIT(n)
+#define STAMP2(k)
 #define STAMP(k)
 #define STAMP_FLAG(v)
 #endif
@@ -751,8 +754,11 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 if (m == 0) continue;
                 bf_pop = (v_moves && v_len >= v_grow + 2 * __builtin_popcount(v_em)) ? 1u : 0u;  // lanes <= s are final
                 bf_moved = (uint32_t)mvmask & ((2u << s) - 1u);
+                STAMP2(0);
                 ensure_draws((uint32_t)__builtin_popcount(m));
+                STAMP2(1);
                 build_free();
+                STAMP2(2);
                 while (m) {
                     const int f = __builtin_ffs((int)m) - 1;
                     m &= m - 1;
@@ -761,6 +767,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                     const uint32_t bit = (uint32_t)v_nh == c ? (1u << f) : 0u;
                     v_em = (v_moves && lane > s) ? ((v_em & ~(1u << f)) | bit) : v_em;
                 }
+                STAMP2(3);
             }
             bf_moved = 0;
         }

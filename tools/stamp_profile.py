@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-buf = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+buf = torch.zeros((2 * n, 8), dtype=torch.int64, device="cuda")
 os.environ["MSNAKE_DBG_BUF"] = hex(buf.data_ptr())
 import msnake
 
@@ -25,7 +25,12 @@ for rep in range(20):
     torch.cuda.synchronize()
     env.step_device(tape[200 + rep])
     torch.cuda.synchronize()
-    b = buf.cpu().numpy().astype(np.int64)
+    ball = buf.cpu().numpy().astype(np.int64)
+    b, b2 = ball[:n], ball[n:]
+    eat = (b[:, 7] & 1) == 1
+    if eat.any():  # inside the respawn path (second stamp row): since the move section began
+        d2 = np.stack([(b2[eat, 0] - b[eat, 1]), (b2[eat, 1] - b2[eat, 0]), (b2[eat, 2] - b2[eat, 1]), (b2[eat, 3] - b2[eat, 2]), (b[eat, 2] - b2[eat, 3])], 1) / 100.0
+        acc.setdefault("eat_split", []).append(np.median(d2, 0))
     t0 = b[:, 0].min()
     us = (b[:, :7] - t0) / 100.0
     flag = b[:, 7]
@@ -43,6 +48,9 @@ print(f"  wave life      median {np.median(life):.2f}  p90 {np.percentile(life, 
 order = np.argsort(us[:, 0])
 late = order[-256:]
 print(f"  the 256 waves that start last: life median {np.median(life[late]):.2f}; stage medians " + " ".join(f"{np.median(dur[late, i]):.2f}" for i in range(6)))
+if "eat_split" in acc:
+    m = np.mean(acc["eat_split"], 0)
+    print("--- respawn path of the waves that eat, median us: vector prologue %.2f, draws %.2f, free-cell map %.2f, pick + record %.2f, rest of the move section %.2f" % tuple(m))
 for cls in ("all", "fast", "eat", "done"):
     if cls not in acc:
         continue
