@@ -246,11 +246,12 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // every aligned group of 64 workgroups XCD x takes 8 CONSECUTIVE env blocks (bits 0-2 and 3-5 of
     // the id swapped).  Each XCD's L2 then writes runs of 8 workgroups' envs of the observation tensor
     // (127-254 KB contiguous) instead of single-workgroup pieces whose edge cache lines it shares with two other XCDs.
-    // An incomplete last group keeps the identity mapping.  (Measured: 0.4 % less WRITE_SIZE, launch
-    // time unchanged -- the envs share nothing else across workgroups.)
+    // (Measured: 0.4 % less WRITE_SIZE, launch time unchanged -- the envs share nothing else across workgroups.)
     const uint32_t epb = (pk2 >> PK2_EPB_SHIFT) & 0xFFu;  // = blockDim.x / 64, without the scalar-memory round trip
+    // (the launch glue rounds the grid up to whole groups of 64 workgroups, so the swap is a permutation of
+    //  every group; workgroups it maps beyond the batch leave)
     uint32_t b = blockIdx.x;
-    if ((b | 63u) * epb < (uint32_t)nenv) b = (b & ~63u) | ((b & 7u) << 3) | ((b >> 3) & 7u);
+    b = (b & ~63u) | ((b & 7u) << 3) | ((b >> 3) & 7u);
     const int e = (int)(b * epb) + wave;
     if (e >= nenv) return;
 
@@ -276,6 +277,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         // snake_env / adversarial can run on the first 128 bytes of the record (no parked Philox draws)
         short_rec = RULES != MSNAKE_RULES_NEW_WORLD && (pk2v & PK2_SHORT_REC);
         W = dim + 2; n2 = dim * dim;
+    };
+    auto lds_layout = [&]() {
         // LDS image: W rows of W*K pixels (already replicated horizontally when K > 1), padded to
         // whole 1 KiB wave-instructions
         img_bytes = (S * K + 1023) & ~1023;
@@ -344,6 +347,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // (every lane loads -- lanes >= NS re-read the last snake's action, which nothing looks at -- instead of
     //  an exec-mask region around three lanes)
     if (MODE == 0) actv = actions[(uint32_t)e * (uint32_t)action_stride + (uint32_t)(lane < NS ? lane : NS - 1)];
+    // (the state loads above are in flight before anything else of the entry block is computed)
+    __builtin_amdgcn_sched_barrier(0);
+    lds_layout();
     // adversarial rules keep a growing fruit LIST ([A]:183-185 appends dead bodies to it): entries
     // 0..63 in a VGPR like a body chunk (lane l = entry l), the complete list in HBM behind the rings
     const int fcap = (NS + NS * (n2 + 2) + 63) & ~63;
@@ -605,6 +611,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     if (MODE == 3) {
         asm volatile("" : "+v"(lane), "+s"(pk0v), "+s"(pk1v), "+s"(pk2v));
         unpack();
+        lds_layout();
         __builtin_amdgcn_s_setprio(0);  // (a slow path of the previous step raised it)
     }
     // MODE 3 issues NO vector-memory load in a normal step: gfx9 has one counter for loads and
@@ -1520,7 +1527,7 @@ static hipError_t launch_k(const StepParams& p, int mode, int epb, hipStream_t s
     const uint32_t pk2 = (p.short_rec ? PK2_SHORT_REC : 0u) | (p.rest.stream_obs ? PK2_STREAM_OBS : 0u) |
                          (p.stream_tape ? PK2_STREAM_TAPE : 0u) | ((uint32_t)epb << PK2_EPB_SHIFT) |
                          (div_magic((uint32_t)p.dim) << PK2_DIVM_SHIFT);
-    const dim3 grid((unsigned)((p.nenv + epb - 1) / epb));
+    const dim3 grid((unsigned)((((p.nenv + epb - 1) / epb) + 63) & ~63));  // whole groups of 64: see the kernel's XCD swap
     const dim3 block(64u * (unsigned)epb);
 #define MSNAKE_LAUNCH(M)                                                                                       \
     hipLaunchKernelGGL((msnake_step_kernel<RULES, NS, M, K>), grid, block, lds, stream, p.state, p.obs, p.actions, \
