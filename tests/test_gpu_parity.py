@@ -120,6 +120,16 @@ def test_config3_4096_envs_19x19_3snakes():
     assert _run_vs_oracle(4096, 19, 3, 3, "snake_env", 200, seed=0) > 1000
 
 
+@pytest.mark.parametrize("rules,dim,ns,nf", [("snake_env", 62, 3, 3), ("snake_env", 33, 2, 2), ("snake_env", 47, 3, 3),
+                                             ("adversarial", 62, 3, 3), ("new_world", 62, 3, 20), ("new_world", 41, 4, 32)])
+def test_large_boards_respawn_cell_split(rules, dim, ns, nf):
+    """Boards up to MSNAKE_MAX_DIM: a respawned fruit's cell comes from x / dim, x % dim of a free-cell index
+    x < dim^2, which the kernel computes with a multiplier from the launch glue instead of a division.  On a big
+    board random play rarely eats, so the snakes are steered less (more straight runs over more fruits)."""
+    n = 192 if dim > 50 else 256
+    assert _run_vs_oracle(n, dim, ns, nf, rules, 160, seed=dim, greedy=0.7) >= 0
+
+
 def test_config3_with_plain_observation_stores(monkeypatch):
     """4 096 envs stream their observation stores by default; batches of 64-130 MiB use plain ones."""
     monkeypatch.setenv("MSNAKE_NT", "0")
