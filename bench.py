@@ -31,6 +31,12 @@ Prints ONE JSON line (rank 0).  Extra keys beside the driver's contract:
                  named in `traffic_source` -- a recorded counter pass of this command, not a live one)
   rollout_tape : the same steps through the persistent msnake_rollout_tape launch, every step's
                  observations going to their own slice of a T x 16.3 MB buffer (never `value`)
+  per_step_strided : the per-step launches again, every step's observations going to their own 16.3 MB slice
+                 of a 64-step buffer, as the caller keeps them (ppo_multi_agent.py:178 mb_obs.append); the
+                 headline leg re-writes ONE buffer (never `value`)
+  selfplay_rollout : BASELINE configs[4] -- 4 096 envs x 2 snakes driving a 16-step self-play rollout
+                 (msnake.selfplay.Runner: CnnPolicy learner + opponent on the same GPU, ppo_multi_agent.py:
+                 170-216): frames/s of the rollout and the env's share of its time (never `value`)
   cpu_baseline : the CPU oracle (oracle/snake_oracle.c, the parity-pinned port of the reference)
                  timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -98,6 +104,46 @@ def cpu_baseline(actions_host, seconds=12.0):
             "one_core_value": round(one, 1)}
 
 
+def selfplay_rollout_leg(dev, n=4096, nsteps=16):
+    """BASELINE configs[4]: n envs x 2 snakes x 19x19, self-play rollouts with the PyTorch policy in the loop
+    (observations, actions, rewards and dones never leave the GPU).  Reports the rollout's frames/s and how much of
+    a rollout is the env: the same `nsteps` msnake_step launches timed alone with HIP events.  Bounded: one warm-up
+    rollout (MIOpen picks its convolution solvers there) and two timed ones."""
+    import torch
+    import msnake
+    from msnake import selfplay
+    env = msnake.MultiSnakeVecEnv(n, dim=DIM, n_snakes=2, rules="snake_env", seed=0, device=dev)
+    H, W, _ = env.obs_shape
+    torch.manual_seed(0)
+    model, opp = selfplay.CnnPolicy((H, W, 3)).to(dev), selfplay.CnnPolicy((H, W, 3)).to(dev)
+    runner = selfplay.Runner(env, model, [opp], nsteps, 0.99, 0.95)
+    runner.run()
+    torch.cuda.synchronize()
+    wall = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        runner.run()
+        torch.cuda.synchronize()
+        wall.append(time.perf_counter() - t0)
+    full = runner.multi_step()[3]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    env.step_device(full)
+    e0.record()
+    for _ in range(nsteps):
+        env.step_device(full)
+    e1.record()
+    torch.cuda.synchronize()
+    env_ms = e0.elapsed_time(e1)
+    st = env.stats()
+    env.close()
+    t = statistics.median(wall)
+    return {"what": f"{n} envs x 2 snakes x {DIM}x{DIM} (BASELINE configs[4]), {nsteps}-step self-play rollout: "
+                    "selfplay.Runner.run = learner + opponent CnnPolicy inference (fp32, MIOpen) + msnake_step + GAE, all on the GPU",
+            "frames_per_s": round(n * nsteps / t, 1), "rollout_ms": round(t * 1e3, 2),
+            "env_us_per_step": round(env_ms * 1e3 / nsteps, 2), "env_share_of_rollout": round(env_ms * 1e-3 / t, 5),
+            "env_errors": int(st["errors"])}
+
+
 def load_pmc_traffic(bytes_per_launch):
     """(HBM bytes per launch, source) from the newest committed PMC pass of THIS workload
     (profiles/hbm_traffic_*.json: separate FETCH_SIZE / WRITE_SIZE passes of this same command,
@@ -141,7 +187,11 @@ def main():
     ap.add_argument("--repeats", type=int, default=0, help="timed repeats of the K-step region (default max(5, ceil(2048/K)))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--python-loop", action="store_true", help="issue launches from Python instead of msnake_step_tape")
-    ap.add_argument("--no-rollout", action="store_true", help="skip the secondary msnake_rollout_tape leg (profiling)")
+    ap.add_argument("--no-rollout", action="store_true",
+                    help="skip the secondary legs: msnake_rollout_tape, per_step_strided, selfplay_rollout (profiling)")
+    ap.add_argument("--epb", type=int, default=0, help="msnake_config.envs_per_block (0 = auto)")
+    ap.add_argument("--record-policy", default="auto", choices=["auto", "full", "short"])
+    ap.add_argument("--store-policy", default="auto", choices=["auto", "plain", "stream"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + MSNAKE_BENCH_ONE_DEVICE=1 rehearses the N>1 path with every rank on cuda:0")
     args = ap.parse_args()
@@ -155,7 +205,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # under torchrun -- also with ONE rank: the collective path (RCCL) is then the real one
+    if all(k in os.environ for k in ("WORLD_SIZE", "RANK", "MASTER_ADDR", "MASTER_PORT")):
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if os.environ.get("MSNAKE_BENCH_ONE_DEVICE") == "1":
@@ -176,7 +227,8 @@ def main():
     R = args.repeats if args.repeats > 0 else max(5, math.ceil(2048 / max(1, K)))
 
     # rank r owns the global env ids [r*n, (r+1)*n): the shipped sharding API, not a hand-rolled one
-    env = msnake.make_sharded(n * world, rank, world, device=dev, dim=DIM, n_snakes=N_SNAKES, rules="snake_env", seed=0)
+    env = msnake.make_sharded(n * world, rank, world, device=dev, dim=DIM, n_snakes=N_SNAKES, rules="snake_env", seed=0,
+                              envs_per_block=args.epb, record_policy=args.record_policy, obs_store_policy=args.store_policy)
     assert env.num_envs == n and env.cfg.env_id_base == rank * n
     # synthetic input: uniform random actions in [0,5), one tape shared by the GPU and CPU runs
     T = TAPE_STEPS
@@ -270,6 +322,38 @@ def main():
         env.stats(reset=True)
         del obs_t
 
+    # secondary figure: per-step launches whose observations go to a per-step slice, as Runner.run keeps them
+    strided = None
+    if rank == 0 and not args.python_loop and not args.no_rollout:
+        S = H * Wd * C
+        Ts = max(2, min(64, (8 << 30) // (n * S)))  # 64 steps of 16.3 MB at the bench batch; at most 8 GB
+        obs_s = torch.empty((Ts, n, H, Wd, C), dtype=torch.uint8, device=dev)
+
+        def run_strided(nsteps):
+            k = 0
+            while k < nsteps:
+                off = k % T
+                m = min(nsteps - k, Ts, T - off)
+                msnake._capi.check(L.msnake_step_tape(h, tape[off].data_ptr(), N_SNAKES, m, obs_s.data_ptr(), n * S,
+                                                      rew.data_ptr(), done.data_ptr(), info.data_ptr(), 0,
+                                                      env._stream()), "msnake_step_tape")
+                k += m
+        Ks = max(K, Ts)
+        run_strided(Ts)
+        torch.cuda.synchronize()
+        ss = []
+        for _ in range(5):
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            env.render_device()
+            s0.record()
+            run_strided(Ks)
+            s1.record()
+            torch.cuda.synchronize()
+            ss.append(s0.elapsed_time(s1) * 1e3 / Ks)
+        strided = (statistics.median(ss), Ts, Ks)
+        env.stats(reset=True)
+        del obs_s
+
     # the only collective of the path: all-gather of the per-rank episode statistics (RCCL on GPUs)
     per_rank, total = msnake.gather_stats(st)
     cdev = dev if (dist and args.backend == "nccl") else torch.device("cpu")  # collectives run where the backend lives
@@ -317,6 +401,16 @@ def main():
                 "us_per_step": round(rollout, 3), "env_steps_per_s": round(n / rollout * 1e6, 1),
                 "algorithmic_GBs": round(bytes_per_launch / rollout / 1e3, 1),
                 "algorithmic_frac_of_hbm_peak": round(bytes_per_launch / rollout / 1e3 / HBM_PEAK_GBS, 4)}
+        if strided is not None:
+            us, Ts, Ks = strided
+            out["per_step_strided"] = {
+                "what": f"msnake_step launches whose observations go to per-step slices of a {Ts} x {n * H * Wd * C / 1e6:.1f} MB buffer "
+                        f"(obs_step_stride = one batch), {Ks} steps, median of 5",
+                "us_per_step": round(us, 3), "env_steps_per_s": round(n / us * 1e6, 1),
+                "algorithmic_frac_of_hbm_peak": round(bytes_per_launch / us / 1e3 / HBM_PEAK_GBS, 4)}
+        out["collective"] = {"backend": total.get("backend"), "record_device": total.get("record_device"), "ranks": len(per_rank)}
+        if world == 1 and not args.no_rollout and not args.python_loop:
+            out["selfplay_rollout"] = selfplay_rollout_leg(dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(tape_h)
         print(json.dumps(out), flush=True)

@@ -25,6 +25,7 @@
  *   msnake_get_state / msnake_set_state / msnake_get_state_all / msnake_set_state_all: no reference
  *                      counterpart (env state is never checkpointed there); used by
  *                      the parity tests to install hand-built states and by callers to checkpoint.
+ *   msnake_state_blob_info: no reference counterpart either; validates such a checkpoint on the host.
  *   msnake_get_stats <- the epinfobuf aggregation in ppo_multi_agent.py:288,331,366-390
  *
  * RNG contract (shared with oracle/ and tests/golden): draw i of global env g is word (i & 3) of
@@ -42,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MSNAKE_ABI_VERSION 2
+#define MSNAKE_ABI_VERSION 3
 
 /* rule sets = the reference's gym ids (gym-snake/gym_snake/__init__.py:11-26) */
 #define MSNAKE_RULES_SNAKE_ENV 0   /* snake-multiple-test-v0  : SnakeEnv            */
@@ -74,7 +75,22 @@ typedef struct msnake_config {
     int32_t obs_scale;     /* integer pixel replication of the observation (1 = native)     */
     uint64_t seed;         /* Philox key                                                    */
     uint64_t env_id_base;  /* global id of local env 0 (Philox subsequence = base + index)  */
+    /* ---- ABI 3: launch tuning, all optional (0 = the library decides from the batch size).
+     *      They change how the work is laid out on the GPU, never a result: every value is parity-tested.
+     *      A caller built against ABI 2 passes struct_size = MSNAKE_CONFIG_SIZE_V2 (the fields above);
+     *      the tail is then taken as zeros. */
+    int32_t envs_per_block;    /* envs (= wavefronts) per workgroup: 0 auto | 1..8                      */
+    int32_t record_policy;     /* MSNAKE_AUTO | MSNAKE_RECORD_FULL | MSNAKE_RECORD_SHORT (snake_env / adversarial) */
+    int32_t obs_store_policy;  /* MSNAKE_AUTO | MSNAKE_STORE_PLAIN | MSNAKE_STORE_STREAM: msnake_step / reset / render */
+    int32_t tape_store_policy; /* the same for msnake_rollout_tape                                      */
 } msnake_config;
+
+#define MSNAKE_CONFIG_SIZE_V2 56u
+#define MSNAKE_AUTO 0
+#define MSNAKE_RECORD_FULL 1  /* 256-byte env record: the upper half parks Philox draws between launches */
+#define MSNAKE_RECORD_SHORT 2 /* only the first 128 bytes of the record move (bandwidth-bound batches)   */
+#define MSNAKE_STORE_PLAIN 1  /* observation stores stay in L2 / Infinity Cache                          */
+#define MSNAKE_STORE_STREAM 2 /* observation stores carry the nt (streaming) hint                        */
 
 /* per-env info written by msnake_step, 16 bytes, same meaning as the reference's info dict */
 typedef struct msnake_info {
@@ -139,8 +155,10 @@ int msnake_rollout_tape(msnake_handle h, const int32_t* actions_dev, int32_t act
 
 /* Canonical per-env state as int32 words (blocking; test / checkpoint path):
  *  [0] t  [1] ctr_lo  [2] ctr_hi  [3] spare_fruits  [4] ep_len  [5] ep_return (f32 bits)
- *  [6] n_fruits_cur  [7] n_snakes, then n_fruits_cur x (c0,c1), then per snake:
+ *  [6] n_fruits_cur  [7] n_snakes | finished << 8, then n_fruits_cur x (c0,c1), then per snake:
  *  len, v0, v1, grow_to, alive, in_dead, len x (c0,c1) head first.
+ * `finished` (bit 8 of word 7): the episode has ended and the env has not been reset since (only ever set
+ * with auto_reset = 0); it keeps a restored env from counting that episode into msnake_get_stats again.
  * Heads and the entries of the adversarial fruit list lie in [-1, dim] (one step outside the grid is
  * where the reference can put them); body pieces behind the head and the fruits of snake_env /
  * new_world lie inside the grid [0, dim).  Anything else is MSNAKE_E_STATE.
@@ -150,7 +168,8 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
 
 /* The same canonical words for EVERY env of the handle in one host buffer (blocking; checkpoints):
  * one packing kernel on the device and one copy, instead of num_envs round trips.  Layout of `buf`:
- *   { uint32 magic "MSST", uint32 version, int32 num_envs, dim, n_snakes, n_fruits, rules, reserved,
+ *   { uint32 magic "MSST", uint32 version (2; version-1 blobs, which lack the finished bit, are accepted),
+ *     int32 num_envs, dim, n_snakes, n_fruits, rules, reserved,
  *     uint64 total_words }  (40 bytes)
  *   uint64 offsets[num_envs + 1]   word offset of env e's state inside `words`
  *   int32  words[total_words]      env e's words = words[offsets[e] .. offsets[e+1]), layout as above
@@ -161,6 +180,16 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
  * logging totals (msnake_get_stats) are not part of the canonical state and are kept. */
 int64_t msnake_get_state_all(msnake_handle h, void* buf, size_t cap_bytes);
 int msnake_set_state_all(msnake_handle h, const void* buf, size_t bytes);
+
+/* What a blob holds, checked on the host without a handle or a device: magic / version, the offset table
+ * (starts at 0, never decreases, ends at total_words) and that `bytes` covers all of it.  MSNAKE_E_STATE
+ * otherwise.  Lets a caller size the handle a checkpoint needs before creating it; msnake_set_state_all
+ * runs the same check first.  `out` may be NULL. */
+typedef struct msnake_blob_info {
+    int32_t version, num_envs, dim, n_snakes, n_fruits, rules;
+    int64_t total_words;
+} msnake_blob_info;
+int msnake_state_blob_info(const void* buf, size_t bytes, msnake_blob_info* out);
 
 /* Render the current state of every env without stepping (asynchronous). */
 int msnake_render(msnake_handle h, uint8_t* obs_dev, void* stream);

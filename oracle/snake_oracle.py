@@ -79,7 +79,7 @@ def state_to_flat(st, n_snakes):
     w = [int(st.get("t", 0)), ctr & 0xFFFFFFFF, ctr >> 32, int(st.get("spare_fruits", 0)),
          int(st.get("ep_len", 0)),
          int(np.array([st.get("ep_return", 0.0)], np.float32).view(np.uint32)[0]),
-         len(st["fruits"]), n_snakes]
+         len(st["fruits"]), n_snakes | (0x100 if st.get("finished") else 0)]
     for f in st["fruits"]:
         w += [int(f[0]), int(f[1])]
     for s in range(n_snakes):
@@ -93,13 +93,20 @@ def state_to_flat(st, n_snakes):
     return np.array([x - (1 << 32) if x >= (1 << 31) else x for x in w], dtype=np.int32)
 
 
+def flat_finished(buf):
+    """Bit 8 of word 7 of the PRODUCT's canonical words (include/msnake.h): the episode has ended and the env was
+    not reset since.  A vec-layer bookkeeping bit of the product (episode totals count once); the reference and
+    this oracle have no such state, so flat_to_state() leaves it out of the dict."""
+    return bool(int(buf[7]) & 0x100)
+
+
 def flat_to_state(buf):
     buf = [int(x) for x in buf]
     k = 0
     st = {"t": buf[0], "ctr": (buf[1] & 0xFFFFFFFF) | ((buf[2] & 0xFFFFFFFF) << 32),
           "spare_fruits": buf[3], "ep_len": buf[4],
           "ep_return": float(np.array([buf[5] & 0xFFFFFFFF], np.uint32).view(np.float32)[0])}
-    nf, n = buf[6], buf[7]
+    nf, n = buf[6], buf[7] & 0xFF
     k = 8
     st["fruits"] = [[buf[k + 2 * i], buf[k + 2 * i + 1]] for i in range(nf)]
     k += 2 * nf

@@ -17,7 +17,7 @@ RULE_NAMES = {v: k for k, v in RULES.items()}
 SYMBOLS = [
     "msnake_abi_version", "msnake_last_error", "msnake_create", "msnake_destroy", "msnake_obs_shape",
     "msnake_reset", "msnake_step", "msnake_step_tape", "msnake_rollout_tape", "msnake_get_state", "msnake_set_state",
-    "msnake_get_state_all", "msnake_set_state_all",
+    "msnake_get_state_all", "msnake_set_state_all", "msnake_state_blob_info",
     "msnake_render", "msnake_get_stats", "msnake_kernel_name", "msnake_algorithmic_bytes_per_env_step",
 ]
 
@@ -26,7 +26,22 @@ class MsnakeConfig(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("num_envs", ctypes.c_int32),
                 ("dim", ctypes.c_int32), ("n_snakes", ctypes.c_int32), ("n_fruits", ctypes.c_int32),
                 ("rules", ctypes.c_int32), ("max_steps", ctypes.c_int32), ("auto_reset", ctypes.c_int32),
-                ("obs_scale", ctypes.c_int32), ("seed", ctypes.c_uint64), ("env_id_base", ctypes.c_uint64)]
+                ("obs_scale", ctypes.c_int32), ("seed", ctypes.c_uint64), ("env_id_base", ctypes.c_uint64),
+                # ABI 3: launch tuning, 0 = the library decides
+                ("envs_per_block", ctypes.c_int32), ("record_policy", ctypes.c_int32),
+                ("obs_store_policy", ctypes.c_int32), ("tape_store_policy", ctypes.c_int32)]
+
+
+ABI_VERSION = 3
+CONFIG_SIZE_V2 = 56
+RECORD_POLICY = {"auto": 0, "full": 1, "short": 2}
+STORE_POLICY = {"auto": 0, "plain": 1, "stream": 2}
+
+
+class MsnakeBlobInfo(ctypes.Structure):
+    _fields_ = [("version", ctypes.c_int32), ("num_envs", ctypes.c_int32), ("dim", ctypes.c_int32),
+                ("n_snakes", ctypes.c_int32), ("n_fruits", ctypes.c_int32), ("rules", ctypes.c_int32),
+                ("total_words", ctypes.c_int64)]
 
 
 class MsnakeStats(ctypes.Structure):
@@ -71,6 +86,7 @@ def load():
     L.msnake_get_state_all.argtypes = [vp, vp, ctypes.c_size_t]
     L.msnake_get_state_all.restype = ctypes.c_int64
     L.msnake_set_state_all.argtypes = [vp, vp, ctypes.c_size_t]
+    L.msnake_state_blob_info.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(MsnakeBlobInfo)]
     L.msnake_get_stats.argtypes = [vp, ctypes.POINTER(MsnakeStats), i32]
     L.msnake_kernel_name.argtypes = [vp]
     L.msnake_kernel_name.restype = ctypes.c_char_p
@@ -78,7 +94,7 @@ def load():
     L.msnake_algorithmic_bytes_per_env_step.restype = ctypes.c_int64
     for name in ("msnake_create", "msnake_destroy", "msnake_obs_shape", "msnake_reset", "msnake_render",
                  "msnake_step", "msnake_step_tape", "msnake_rollout_tape", "msnake_get_state", "msnake_set_state", "msnake_set_state_all",
-                 "msnake_get_stats"):
+                 "msnake_state_blob_info", "msnake_get_stats"):
         getattr(L, name).restype = ctypes.c_int
     _lib = L
     return L

@@ -59,6 +59,9 @@ struct msnake_env {
     void* d_scratch;       // per-env state import/export staging (grown on demand)
     size_t scratch_bytes;
     char kname[64];
+    // MSNAKE_DBG_STAGES builds only (tools/span_gap.py): per-launch slots of wave stamps
+    unsigned long long* dbg_span;
+    uint32_t dbg_span_slots, dbg_launch;
 };
 
 namespace {
@@ -96,12 +99,18 @@ extern "C" {
 int msnake_abi_version(void) { return MSNAKE_ABI_VERSION; }
 const char* msnake_last_error(void) { return g_err; }
 
-int msnake_create(const msnake_config* cfg, msnake_handle* out) {
-    if (!cfg || !out) return fail(MSNAKE_E_ARG, "msnake_create: NULL argument");
+int msnake_create(const msnake_config* cfg_in, msnake_handle* out) {
+    if (!cfg_in || !out) return fail(MSNAKE_E_ARG, "msnake_create: NULL argument");
     *out = nullptr;
-    if (cfg->struct_size != sizeof(msnake_config))
-        return fail(MSNAKE_E_ARG, "msnake_config.struct_size %u != %zu (ABI mismatch)", cfg->struct_size,
-                    sizeof(msnake_config));
+    // ABI 3 appended the launch-tuning fields; an ABI-2 caller passes the 56-byte prefix and gets "auto"
+    if (cfg_in->struct_size != sizeof(msnake_config) && cfg_in->struct_size != MSNAKE_CONFIG_SIZE_V2)
+        return fail(MSNAKE_E_ARG, "msnake_config.struct_size %u is neither %zu (ABI 3) nor %u (ABI 2)", cfg_in->struct_size,
+                    sizeof(msnake_config), MSNAKE_CONFIG_SIZE_V2);
+    msnake_config cfg_full;
+    memset(&cfg_full, 0, sizeof(cfg_full));
+    memcpy(&cfg_full, cfg_in, cfg_in->struct_size);
+    cfg_full.struct_size = (uint32_t)sizeof(msnake_config);
+    const msnake_config* cfg = &cfg_full;
     if (cfg->num_envs < 1) return fail(MSNAKE_E_ARG, "num_envs must be >= 1 (got %d)", cfg->num_envs);
     if (cfg->dim < 2 || cfg->dim > MSNAKE_MAX_DIM)
         return fail(MSNAKE_E_ARG, "dim must be in [2, %d] (got %d)", MSNAKE_MAX_DIM, cfg->dim);
@@ -128,6 +137,13 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
                                   "addresses them with 32-bit offsets); use several handles", cfg->num_envs);
     if (cfg->obs_scale != 1 && cfg->obs_scale != 4 && cfg->obs_scale != 7)
         return fail(MSNAKE_E_ARG, "obs_scale must be 1, 4 (21->84) or 7 (12->84), got %d", cfg->obs_scale);
+    if (cfg->envs_per_block < 0 || cfg->envs_per_block > MSNAKE_MAX_ENVS_PER_BLOCK)
+        return fail(MSNAKE_E_ARG, "envs_per_block must be 0 (auto) or in [1, %d], got %d", MSNAKE_MAX_ENVS_PER_BLOCK, cfg->envs_per_block);
+    if (cfg->record_policy < 0 || cfg->record_policy > MSNAKE_RECORD_SHORT)
+        return fail(MSNAKE_E_ARG, "record_policy must be MSNAKE_AUTO, MSNAKE_RECORD_FULL or MSNAKE_RECORD_SHORT, got %d", cfg->record_policy);
+    if (cfg->obs_store_policy < 0 || cfg->obs_store_policy > MSNAKE_STORE_STREAM || cfg->tape_store_policy < 0 ||
+        cfg->tape_store_policy > MSNAKE_STORE_STREAM)
+        return fail(MSNAKE_E_ARG, "obs_store_policy / tape_store_policy must be MSNAKE_AUTO, MSNAKE_STORE_PLAIN or MSNAKE_STORE_STREAM");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -211,17 +227,15 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
         free(h);
         return fail(MSNAKE_E_HIP, "uploading the background image failed: %s", hipGetErrorString(e));
     }
-    if (const char* epb = getenv("MSNAKE_EPB")) {  // tuning knob: envs (waves) per workgroup, 1..8
-        const int v = atoi(epb);
-        if (v >= 1 && v <= h->epb) h->epb = v;
-    }
+    if (cfg->envs_per_block > 0 && cfg->envs_per_block < h->epb) h->epb = cfg->envs_per_block;  // (never above what LDS allows)
     // record_policy: snake_env / adversarial steps can run on the first 128 bytes of the 256-byte
     // record; the upper half only parks Philox draws for the waves that respawn or reset, which pays
     // while a launch is latency bound (<= 8 192 envs) and is pure traffic above
     p.short_rec = (cfg->rules != MSNAKE_RULES_NEW_WORLD && p.nenv > 8192) ? 1 : 0;
-    if (const char* sr = getenv("MSNAKE_SHORT_REC")) p.short_rec = (cfg->rules != MSNAKE_RULES_NEW_WORLD && atoi(sr)) ? 1 : 0;
+    if (cfg->record_policy != MSNAKE_AUTO)  // (new_world keeps its fruits in the upper half: always the full record)
+        p.short_rec = (cfg->rules != MSNAKE_RULES_NEW_WORLD && cfg->record_policy == MSNAKE_RECORD_SHORT) ? 1 : 0;
     // obs_store_policy: should the observation stores carry the nt (streaming) hint?  Measured on
-    // MI355X with the native 16-byte-per-lane copy-out (tools/kbench.py, MSNAKE_NT=0/1), per launch:
+    // MI355X with the native 16-byte-per-lane copy-out (tools/kbench.py --store-policy plain/stream), per launch:
     //   <= 32 MiB of observations (<= 8 192 envs at 19x19x3; fits the 8 L2s): 2-3 % faster with nt
     //      (nothing is left to write back when the kernel ends);
     //   64-130 MiB (fits the 256 MB Infinity Cache): 0-4 % slower (a re-used buffer no longer hits);
@@ -232,10 +246,16 @@ int msnake_create(const msnake_config* cfg, msnake_handle* out) {
         const double obs_mib = (double)p.nenv * p.S * p.obs_scale * p.obs_scale / (1024.0 * 1024.0);
         p.rest.stream_obs = (p.obs_scale == 1 && (obs_mib <= 32.0 || obs_mib >= 192.0)) ? 1u : 0u;
     }
-    if (const char* nt = getenv("MSNAKE_NT")) p.rest.stream_obs = atoi(nt) ? 1u : 0u;  // experiment knob
+    if (cfg->obs_store_policy != MSNAKE_AUTO) p.rest.stream_obs = cfg->obs_store_policy == MSNAKE_STORE_STREAM ? 1u : 0u;
 #ifdef MSNAKE_DBG_STAGES  // diagnostic builds only (tools/stamp_profile.py): never in the shipped library
     if (const char* dbg = getenv("MSNAKE_DBG_STAGE")) p.rest.dbg_stage = (uint32_t)atoi(dbg);
     if (const char* dbg = getenv("MSNAKE_DBG_BUF")) p.rest.dbg_buf = reinterpret_cast<unsigned long long*>(strtoull(dbg, nullptr, 0));
+    if (const char* dbg = getenv("MSNAKE_DBG_SPAN")) {  // base of a caller-owned [MSNAKE_DBG_SPAN_SLOTS][num_envs][4] u64 device buffer
+        h->dbg_span = reinterpret_cast<unsigned long long*>(strtoull(dbg, nullptr, 0));
+        const char* sl = getenv("MSNAKE_DBG_SPAN_SLOTS");
+        h->dbg_span_slots = sl ? (uint32_t)atoi(sl) : 1u;
+        if (h->dbg_span_slots < 1) h->dbg_span_slots = 1;
+    }
 #endif
     msnake::step_kernel_name(cfg->rules, cfg->n_snakes, cfg->obs_scale, h->kname, sizeof(h->kname));
     h->magic = kMagic;
@@ -271,6 +291,10 @@ static int launch(msnake_handle h, int mode, const int32_t* actions, int32_t act
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (obs && p.obs_scale > 1 && ((uintptr_t)obs & 3))  // the fused x4 / x7 copy-out stores dwords
         return fail(MSNAKE_E_ALIGN, "obs_dev must be 4-byte aligned when obs_scale > 1");
+#ifdef MSNAKE_DBG_STAGES
+    if (h->dbg_span && mode == 0)  // every msnake_step launch stamps into its own slot (they wrap)
+        p.rest.dbg_span = h->dbg_span + (size_t)(h->dbg_launch++ % h->dbg_span_slots) * (size_t)p.nenv * 4;
+#endif
     hipError_t e = msnake::launch_step(p, h->cfg.rules, mode, h->epb, s);
     if (e != hipSuccess) return fail(MSNAKE_E_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return MSNAKE_OK;
@@ -330,13 +354,9 @@ int msnake_rollout_tape(msnake_handle h, const int32_t* actions_dev, int32_t act
     p.actions = actions_dev; p.action_stride = action_stride;
     p.obs = obs_dev; p.rest.rew = rew_dev; p.rest.done = done_dev; p.rest.info = info_dev;
     p.rest.n_steps = n_steps;
-    // tape_store_policy: the persistent kernel never streams by default (knob for experiments only)
-    {
-        const double mib = (double)n_steps * p.nenv * p.S * p.obs_scale * p.obs_scale / (1024.0 * 1024.0);
-        (void)mib;
-        p.stream_tape = 0;  // measured at 4 096 envs x 256 steps (4.2 GB): 3.9 us per step plain, 4.5 us streaming
-        if (const char* nt = getenv("MSNAKE_NT_TAPE")) p.stream_tape = atoi(nt) ? 1 : 0;  // experiment knob
-    }
+    // tape_store_policy: the persistent kernel does not stream unless the caller asks for it
+    // (measured at 4 096 envs x 256 steps = 4.2 GB: 3.9 us per step plain, 4.5 us streaming)
+    p.stream_tape = h->cfg.tape_store_policy == MSNAKE_STORE_STREAM ? 1 : 0;
     p.rest.obs_step_stride = obs_step_stride;
     p.rest.scalar_step_stride = scalar_step_stride;
     if (obs_dev && p.obs_scale > 1 && (((uintptr_t)obs_dev | obs_step_stride) & 3))
@@ -359,6 +379,7 @@ struct BlobHeader {  // msnake_get_state_all / msnake_set_state_all
     uint64_t total_words;
 };
 constexpr uint32_t kBlobMagic = 0x5453534Du;  // "MSST"
+constexpr uint32_t kBlobVersion = 2u;         // 2: word 7 of an env's words carries the "episode finished" bit
 
 // need[i] (words) of envs [env0, env0 + count) -> host; offsets[count + 1] prefix sums
 int state_offsets(msnake_env* h, int env0, int count, std::vector<uint64_t>& offsets) {
@@ -387,7 +408,7 @@ int state_import(msnake_env* h, int env0, int count, const uint64_t* offsets, co
     const size_t off_bytes = ((size_t)count + 1) * 8, word_bytes = (size_t)offsets[count] * 4;
     if (int rc = ensure_scratch(h, 16 + off_bytes + word_bytes)) return rc;
     uint8_t* d = static_cast<uint8_t*>(h->d_scratch);
-    const uint32_t st0[4] = {0u, 0xFFFFFFFFu, 0u, 0u};
+    const uint32_t st0[4] = {0u, 0xFFFFFFFFu, 0u, 0u};  // [0] rejected envs, [1] min over them of (local index + 1) << 8 | reason
     HIP_TRY(hipMemcpy(d, st0, 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d + 16, offsets, off_bytes, hipMemcpyHostToDevice));
     if (word_bytes) HIP_TRY(hipMemcpy(d + 16 + off_bytes, words, word_bytes, hipMemcpyHostToDevice));
@@ -398,7 +419,7 @@ int state_import(msnake_env* h, int env0, int count, const uint64_t* offsets, co
     HIP_TRY(hipMemcpy(st, d, 16, hipMemcpyDeviceToHost));
     if (st[0] != 0)
         return fail(MSNAKE_E_STATE, "%u env state(s) rejected; first: env %d: %s (the rejected envs were left untouched)", st[0],
-                    env0 + (int)st[1] - 1, state_reason(st[2]));
+                    env0 + (int)(st[1] >> 8) - 1, state_reason(st[1] & 0xFFu));
     return MSNAKE_OK;
 }
 
@@ -421,7 +442,7 @@ int msnake_set_state(msnake_handle h, int32_t env, const int32_t* words, int32_t
     if (int rc = check(h)) return rc;
     if (env < 0 || env >= h->p.nenv) return fail(MSNAKE_E_ARG, "env %d out of range", env);
     if (!words || n < 8) return fail(MSNAKE_E_STATE, "state buffer too short");
-    if (words[7] != h->p.n_snakes) return fail(MSNAKE_E_STATE, "state has %d snakes, handle has %d", words[7], h->p.n_snakes);
+    if ((words[7] & 0xFF) != h->p.n_snakes) return fail(MSNAKE_E_STATE, "state has %d snakes, handle has %d", words[7] & 0xFF, h->p.n_snakes);
     DeviceGuard guard(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     const uint64_t offsets[2] = {0, (uint64_t)n};
@@ -438,7 +459,7 @@ int64_t msnake_get_state_all(msnake_handle h, void* buf, size_t cap_bytes) {
     const size_t head = sizeof(BlobHeader) + ((size_t)n + 1) * 8;
     const size_t need = head + (size_t)offsets.back() * 4;
     if (!buf || cap_bytes < need) return (int64_t)need;
-    BlobHeader bh = {kBlobMagic, 1u, n, h->p.dim, h->p.n_snakes, h->p.n_fruits, h->cfg.rules, 0, offsets.back()};
+    BlobHeader bh = {kBlobMagic, kBlobVersion, n, h->p.dim, h->p.n_snakes, h->p.n_fruits, h->cfg.rules, 0, offsets.back()};
     uint8_t* out = static_cast<uint8_t*>(buf);
     memcpy(out, &bh, sizeof(bh));
     memcpy(out + sizeof(bh), offsets.data(), ((size_t)n + 1) * 8);
@@ -446,25 +467,49 @@ int64_t msnake_get_state_all(msnake_handle h, void* buf, size_t cap_bytes) {
     return (int64_t)need;
 }
 
-int msnake_set_state_all(msnake_handle h, const void* buf, size_t bytes) {
-    if (int rc = check(h)) return rc;
+int msnake_state_blob_info(const void* buf, size_t bytes, msnake_blob_info* out) {
+    // host-only: header, offset table and length of a msnake_get_state_all blob, before any handle exists
     if (!buf || bytes < sizeof(BlobHeader)) return fail(MSNAKE_E_STATE, "state blob too short");
     BlobHeader bh;
     memcpy(&bh, buf, sizeof(bh));
-    if (bh.magic != kBlobMagic || bh.version != 1u) return fail(MSNAKE_E_STATE, "not an msnake state blob (magic/version)");
-    const msnake::StepParams& p = h->p;
-    if (bh.num_envs != p.nenv || bh.dim != p.dim || bh.n_snakes != p.n_snakes || bh.rules != h->cfg.rules ||
-        (h->cfg.rules != MSNAKE_RULES_ADVERSARIAL && bh.n_fruits != p.n_fruits))
-        return fail(MSNAKE_E_STATE, "state blob is for %d envs, dim %d, %d snakes, %d fruits, rules %d; the handle differs",
-                    bh.num_envs, bh.dim, bh.n_snakes, bh.n_fruits, bh.rules);
-    const size_t n = (size_t)p.nenv, head = sizeof(BlobHeader) + (n + 1) * 8;
-    if (bytes < head) return fail(MSNAKE_E_STATE, "state blob truncated in its offset table");
-    std::vector<uint64_t> offsets(n + 1);
-    memcpy(offsets.data(), static_cast<const uint8_t*>(buf) + sizeof(bh), (n + 1) * 8);
-    if (offsets[0] != 0 || offsets[n] != bh.total_words || bytes < head + (size_t)bh.total_words * 4)
+    if (bh.magic != kBlobMagic || (bh.version != 1u && bh.version != kBlobVersion))
+        return fail(MSNAKE_E_STATE, "not an msnake state blob (magic/version)");
+    if (bh.num_envs < 1) return fail(MSNAKE_E_STATE, "state blob: num_envs %d", bh.num_envs);
+    const size_t n = (size_t)bh.num_envs;
+    if ((bytes - sizeof(BlobHeader)) / 8 < n + 1) return fail(MSNAKE_E_STATE, "state blob truncated in its offset table");
+    const size_t head = sizeof(BlobHeader) + (n + 1) * 8;
+    const uint8_t* offp = static_cast<const uint8_t*>(buf) + sizeof(bh);
+    uint64_t prev = 0, last = 0;
+    memcpy(&prev, offp, 8);
+    memcpy(&last, offp + n * 8, 8);
+    // (the word count is bounded BEFORE it is multiplied: 2^62 words * 4 would wrap to 0 and pass a byte comparison)
+    if (prev != 0 || last != bh.total_words || bh.total_words > (uint64_t)(bytes - head) / 4)
         return fail(MSNAKE_E_STATE, "state blob truncated or its offset table is inconsistent");
-    for (size_t i = 0; i < n; ++i)
-        if (offsets[i + 1] < offsets[i]) return fail(MSNAKE_E_STATE, "state blob: offsets of env %zu decrease", i);
+    for (size_t i = 1; i <= n; ++i) {
+        uint64_t cur;
+        memcpy(&cur, offp + i * 8, 8);
+        if (cur < prev) return fail(MSNAKE_E_STATE, "state blob: offsets of env %zu decrease", i - 1);
+        prev = cur;
+    }
+    if (out) {
+        out->version = (int32_t)bh.version; out->num_envs = bh.num_envs; out->dim = bh.dim; out->n_snakes = bh.n_snakes;
+        out->n_fruits = bh.n_fruits; out->rules = bh.rules; out->total_words = (int64_t)bh.total_words;
+    }
+    return MSNAKE_OK;
+}
+
+int msnake_set_state_all(msnake_handle h, const void* buf, size_t bytes) {
+    if (int rc = check(h)) return rc;
+    msnake_blob_info bi;
+    if (int rc = msnake_state_blob_info(buf, bytes, &bi)) return rc;
+    const msnake::StepParams& p = h->p;
+    if (bi.num_envs != p.nenv || bi.dim != p.dim || bi.n_snakes != p.n_snakes || bi.rules != h->cfg.rules ||
+        (h->cfg.rules != MSNAKE_RULES_ADVERSARIAL && bi.n_fruits != p.n_fruits))
+        return fail(MSNAKE_E_STATE, "state blob is for %d envs, dim %d, %d snakes, %d fruits, rules %d; the handle differs",
+                    bi.num_envs, bi.dim, bi.n_snakes, bi.n_fruits, bi.rules);
+    const size_t n = (size_t)p.nenv, head = sizeof(BlobHeader) + (n + 1) * 8;
+    std::vector<uint64_t> offsets(n + 1);
+    memcpy(offsets.data(), static_cast<const uint8_t*>(buf) + sizeof(BlobHeader), (n + 1) * 8);
     DeviceGuard guard(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     return state_import(h, 0, p.nenv, offsets.data(),

@@ -298,6 +298,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #define STAMP_FLAG(v) if (p.dbg_buf && lane == 0) p.dbg_buf[(size_t)e * 8 + 7] = (v)
 // second row of stamps per env (rows nenv .. 2*nenv-1 of the buffer): inside the respawn path
 #define STAMP2(k) if (p.dbg_buf && lane == 0) p.dbg_buf[((size_t)nenv + (size_t)e) * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
+// span stamps (tools/span_gap.py): one row of 4 per env and LAUNCH (the glue hands every launch its own slot), so that
+// back-to-back launches can be told apart: [0] the wave has started, [1] it has issued its last store, [2] every store
+// of the wave has been acknowledged (it waits for them: only when the span buffer is set)
+#define SPAN(k) if (p.dbg_span && lane == 0) p.dbg_span[(size_t)e * 4 + (k)] = __builtin_amdgcn_s_memrealtime()
 #define DBG_FEWER_STORES(i) && !((dbg & 0x200) && (i) > 0)  /* stage bit 9: timing with a quarter of the observation stores */
 #define DBG_NO_OBS_STORES(S) ((dbg & 0x400) ? 0 : (S))     /* bit 10: ... with none of them */
 #else
@@ -307,6 +311,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #define STAMP2(k)
 #define STAMP(k)
 #define STAMP_FLAG(v)
+#define SPAN(k)
 #endif
     // Section boundary for the register allocator: lane masks (`lane == k`, `lane < k`: an SGPR pair
     // each) computed before it are not kept alive past it.  Only in the instantiations whose peak
@@ -317,6 +322,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // ---- 0. every load whose address depends only on the env index.  One allocation holds
     //         [records | chunk-0 bodies | background image | rings]: one preloaded pointer ---------
     STAMP(0);
+    SPAN(0);
     // (byte offsets in 32 bits: records + body rings of a handle stay below 4 GB, msnake_create checks)
     uint32_t* hdr_g = reinterpret_cast<uint32_t*>(state + (uint32_t)e * (uint32_t)(MSNAKE_HDR_WORDS * 4));
     uint16_t* body0_g = reinterpret_cast<uint16_t*>(state + ((uint32_t)nenv * (uint32_t)(MSNAKE_HDR_WORDS * 4) +
@@ -1250,6 +1256,26 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 
     // ---- 5. state write-back (once per launch): the record; the body rings went out slot by slot --
     if (MODE != 2) {
+#ifndef MSNAKE_NO_LATE_REFILL
+        if (PCACHE && !short_rec) {
+            // Late refill: Philox runs HERE, behind the wave's observation stores (its evaluation overlaps their
+            // latency), whenever the draws parked in the record could no longer cover everything ONE step can ask for
+            // -- NS respawns ([S]: every fruit is eaten at most once per step) and the 4*NS draws of a reset --, so
+            // that no respawning or resetting wave evaluates Philox ahead of its logic in a later launch.
+            // (ensure_draws still does, should a step ever need more: [A] steps that respawn many list fruits.)
+            constexpr uint32_t LOW_WATER = 5u * NS;
+            const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO);
+            bool late;
+            if (refilled)  // Philox already ran (ahead of some logic): again only if what it left cannot fill the parking words
+                late = !(draws_n == 64 && ctr_lo - draw_base + HDR_PC_N <= 64u);
+            else
+                late = rdlane(hv, HDR_PC_VALID) != 1u || ctr_lo - rdlane(hv, HDR_PC_BASE) > HDR_PC_N - LOW_WATER;  // (mod 2^32, like ensure_draws)
+            if (late) {
+                __builtin_amdgcn_s_setprio(3);
+                refill_draws(ctr_lo, rdlane(hv, HDR_CTR_HI));
+            }
+        }
+#endif
         if (PCACHE && refilled && !short_rec) {
             // Philox ran in this launch: its unused draws go into the record for the launches to come
             if (UPPER_TRACKED) upper_dirty = true;
@@ -1271,7 +1297,13 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
         if (RULES == MSNAKE_RULES_ADVERSARIAL && fr_dirty) fl0_of()[lane] = (uint16_t)fr;
     }
-
+#ifdef MSNAKE_DBG_STAGES
+    if (p.dbg_span) {
+        SPAN(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SPAN(2);
+    }
+#endif
 }
 
 // Sum the per-env logging totals into stats[0..4] (msnake_get_stats; off the step path).
@@ -1341,7 +1373,7 @@ __global__ __launch_bounds__(256) void msnake_state_pack_kernel(StateView v, int
     if (lane == 0) {
         out[0] = (int32_t)h[HDR_T]; out[1] = (int32_t)h[HDR_CTR_LO]; out[2] = (int32_t)h[HDR_CTR_HI];
         out[3] = (int32_t)h[HDR_SPARE]; out[4] = (int32_t)h[HDR_EP_LEN]; out[5] = (int32_t)h[HDR_EP_RETURN];
-        out[6] = nfr; out[7] = v.ns;
+        out[6] = nfr; out[7] = v.ns | ((h[HDR_FLAGS] & HDR_FLAG_FINISHED) ? 0x100 : 0);
     }
     size_t k = 8;
     for (int f = lane; f < nfr; f += 64) {
@@ -1378,7 +1410,8 @@ __global__ __launch_bounds__(256) void msnake_state_pack_kernel(StateView v, int
     }
 }
 
-// status[0]: number of rejected envs, status[1]: lowest rejected local index + 1 (atomicMin on ~0u), status[2]: its MSNAKE_ST_* reason
+// status[0]: number of rejected envs, status[1]: min over them of (local index + 1) << 8 | MSNAKE_ST_* reason (ONE
+// atomicMin on ~0u: index and reason of the first rejected env cannot come from two different waves)
 #define MSNAKE_ST_SHORT 1      // buffer too short / truncated
 #define MSNAKE_ST_SNAKES 2     // snake count differs from the handle
 #define MSNAKE_ST_FRUITS 3     // fruit count differs from the handle / exceeds the list capacity
@@ -1399,7 +1432,7 @@ __global__ __launch_bounds__(256) void msnake_state_unpack_kernel(StateView v, i
     int bad = 0;
     int nfr = 0;
     if (n < 8) bad = MSNAKE_ST_SHORT;
-    else if (in[7] != v.ns) bad = MSNAKE_ST_SNAKES;
+    else if ((in[7] & ~0x100) != v.ns) bad = MSNAKE_ST_SNAKES;  // (bit 8: the episode-finished flag)
     else {
         nfr = in[6];
         if (adv ? (nfr < 0 || nfr > v.fcap) : nfr != v.nf) bad = MSNAKE_ST_FRUITS;
@@ -1435,7 +1468,7 @@ __global__ __launch_bounds__(256) void msnake_state_unpack_kernel(StateView v, i
     if (bad) {
         if (lane == 0) {
             atomicAdd(&status[0], 1u);
-            if (atomicMin(&status[1], (uint32_t)w + 1u) > (uint32_t)w + 1u) status[2] = (uint32_t)bad;
+            atomicMin(&status[1], (((uint32_t)w + 1u) << 8) | (uint32_t)bad);
         }
         return;
     }
@@ -1477,6 +1510,7 @@ __global__ __launch_bounds__(256) void msnake_state_unpack_kernel(StateView v, i
         HV_SET(SN_C(s), headc | ((uint32_t)vel << 16));
         k += 6 + 2LL * len;
     }
+    if (in[7] & 0x100) flags |= HDR_FLAG_FINISHED;  // restored as exported: the episode is not counted a second time
     HV_SET_C(HDR_FLAGS, flags);
     h[lane] = hv;
 }

@@ -31,9 +31,10 @@ def gather_stats(local, device=None, group=None):
     import torch.distributed as dist
 
     live = dist.is_available() and dist.is_initialized()
+    backend = str(dist.get_backend(group)) if live else "none"
     if device is None:
         # RCCL ("nccl") moves device tensors only; gloo moves host tensors
-        on_gpu = live and "nccl" in str(dist.get_backend(group)) and torch.cuda.is_available()
+        on_gpu = live and "nccl" in backend and torch.cuda.is_available()
         device = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
     rec = torch.tensor([int(local[k]) for k in STAT_KEYS], dtype=torch.int64, device=device)
     if live:
@@ -46,6 +47,8 @@ def gather_stats(local, device=None, group=None):
     total = {k: sum(r[k] for r in per_rank) for k in STAT_KEYS}
     total["mean_ep_return"] = total["ep_return_sum"] / max(1, total["episodes"])
     total["mean_ep_len"] = total["ep_len_sum"] / max(1, total["episodes"])
+    # where the gathered records lived and what moved them (logging; "cuda:N" + "nccl" = RCCL)
+    total["record_device"], total["backend"] = str(out[0].device), backend
     return per_rank, total
 
 

@@ -398,16 +398,19 @@ def learn(env, nsteps=64, total_timesteps=int(1e6), ent_coef=0.01, lr=lambda f: 
     opt = torch.optim.Adam(model.parameters(), lr=lr(1.0), eps=1e-5)
     first_update, model_idx, next_highscore = 1, 0, 5
     state_file = os.path.join(save_dir, "trainer_state.pt") if save_dir else None
-    if resume and state_file and os.path.exists(state_file):
+    fresh = not (resume and state_file and os.path.exists(state_file))
+    if resume and fresh and save_dir and any(f.startswith("opponent") and f.endswith(".pt") for f in os.listdir(save_dir)):
+        # an interrupted run left its opponent pool but no trainer state: starting over would overwrite the pool
+        # from slot 0 under a model that never saw it
+        raise RuntimeError(f"resume=True: {save_dir} holds opponent files but no trainer_state.pt; "
+                           "pass resume=False to start over (the pool is overwritten) or restore the state file")
+    if not fresh:
         ts = torch.load(state_file, map_location=dev, weights_only=True)
         model.load_state_dict(ts["model"])
         opt.load_state_dict(ts["optimizer"])
         first_update, model_idx, next_highscore = ts["update"] + 1, ts["model_idx"], ts["next_highscore"]
         for pool, (idx, num) in zip(pools, ts["pools"]):
             pool.restore(dev, idx, num)
-    else:
-        for pool in pools:
-            pool.save(model)
 
     def save_trainer_state(update):
         tmp = state_file + ".tmp"
@@ -415,6 +418,12 @@ def learn(env, nsteps=64, total_timesteps=int(1e6), ent_coef=0.01, lr=lambda f: 
                     "model_idx": model_idx, "next_highscore": next_highscore,
                     "pools": [(p.idx, p.num) for p in pools]}, tmp)
         os.replace(tmp, state_file)
+
+    if fresh:
+        for pool in pools:
+            pool.save(model)
+        if save_dir:  # from the first pool file on there is a state a resume can start from
+            save_trainer_state(0)
     runner = Runner(env, model, opponents, nsteps, gamma, lam)
     nbatch = env.num_envs * nsteps
     nbatch_train = nbatch // nminibatches
@@ -458,6 +467,8 @@ def learn(env, nsteps=64, total_timesteps=int(1e6), ent_coef=0.01, lr=lambda f: 
         if update % opponent_save_interval == 0:
             for pool in pools:
                 pool.save(model)
+            if save_dir:  # the pool files and the state file move together: a restore never finds opponents newer
+                save_trainer_state(update)  # than the model / optimizer / update counter it loads
         if update % log_interval == 0 or update == 1:
             lossvals = torch.stack(stats).mean(0).tolist()
             tnow = time.time()

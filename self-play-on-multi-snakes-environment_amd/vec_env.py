@@ -87,7 +87,8 @@ class MultiSnakeVecEnv:
 
     def __init__(self, num_envs, dim=19, n_snakes=3, n_fruits=None, rules="snake_env", seed=0,
                  env_id_base=0, device=None, max_steps=2000, auto_reset=True, obs_scale=1,
-                 declared_channels=6, host_views=False):
+                 declared_channels=6, host_views=False, envs_per_block=0, record_policy="auto",
+                 obs_store_policy="auto", tape_store_policy="auto"):
         import torch  # device memory and streams only
 
         if not torch.cuda.is_available():
@@ -107,7 +108,10 @@ class MultiSnakeVecEnv:
             n_fruits = n_snakes
         self.cfg = _capi.MsnakeConfig(ctypes.sizeof(_capi.MsnakeConfig), self.device.index or 0, int(num_envs),
                                       int(dim), int(n_snakes), int(n_fruits), rules_id, int(max_steps),
-                                      int(bool(auto_reset)), int(obs_scale), int(seed), int(env_id_base))
+                                      int(bool(auto_reset)), int(obs_scale), int(seed), int(env_id_base),
+                                      # launch tuning (msnake_config, ABI 3): how the work is laid out, never a result
+                                      int(envs_per_block), _capi.RECORD_POLICY[record_policy],
+                                      _capi.STORE_POLICY[obs_store_policy], _capi.STORE_POLICY[tape_store_policy])
         self._h = ctypes.c_void_p()
         _capi.check(self._L.msnake_create(ctypes.byref(self.cfg), ctypes.byref(self._h)), "msnake_create")
         H, W, C = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
@@ -286,6 +290,16 @@ class MultiSnakeVecEnv:
     def set_state_all(self, blob):
         b = np.ascontiguousarray(np.frombuffer(blob, np.uint8) if not isinstance(blob, np.ndarray) else blob, dtype=np.uint8)
         _capi.check(self._L.msnake_set_state_all(self._h, b.ctypes.data, b.nbytes), "msnake_set_state_all")
+
+    @staticmethod
+    def blob_info(blob):
+        """What a get_state_all() blob holds (host-only check, no handle needed): dict with version, num_envs,
+        dim, n_snakes, n_fruits, rules (name), total_words.  Raises RuntimeError for a malformed blob."""
+        b = np.ascontiguousarray(np.frombuffer(blob, np.uint8) if not isinstance(blob, np.ndarray) else blob, dtype=np.uint8)
+        bi = _capi.MsnakeBlobInfo()
+        _capi.check(_capi.load().msnake_state_blob_info(b.ctypes.data, b.nbytes, ctypes.byref(bi)), "msnake_state_blob_info")
+        return {"version": bi.version, "num_envs": bi.num_envs, "dim": bi.dim, "n_snakes": bi.n_snakes,
+                "n_fruits": bi.n_fruits, "rules": _capi.RULE_NAMES.get(bi.rules, bi.rules), "total_words": bi.total_words}
 
     def stats(self, reset=False):
         st = _capi.MsnakeStats()

@@ -66,6 +66,58 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _rccl_worker(port, q):
+    """ONE rank on RCCL: the "nccl" branches of msnake.dist / bench.py run for real (a one-GPU box cannot
+    give two RCCL ranks a card each, and RCCL refuses two ranks on one device)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    import msnake
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    env = msnake.make_sharded(4096, dim=19, n_snakes=3, rules="snake_env", seed=SEED)
+    assert env.num_envs == 4096 and env.cfg.env_id_base == 0 and str(env.device) == "cuda:0"
+    env.reset_device()
+    tape = torch.from_numpy(_tape()[:32, :4096].copy()).to(env.device)
+    for t in range(32):
+        env.step_device(tape[t])
+    st = env.stats()
+    per_rank, total = msnake.gather_stats(st)
+    # the same collective by hand on a device tensor, and a barrier: RCCL itself moved these
+    rec = torch.tensor([st["episodes"], st["env_steps"]], dtype=torch.int64, device="cuda:0")
+    out = [torch.zeros_like(rec)]
+    dist.all_gather(out, rec)
+    dist.barrier()
+    torch.cuda.synchronize()
+    q.put({"backend": str(dist.get_backend()), "world": dist.get_world_size(), "per_rank": per_rank, "total": total, "st": st,
+           "by_hand": out[0].tolist(), "by_hand_device": str(out[0].device), "nccl_version": list(torch.cuda.nccl.version())})
+    env.close()
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_group_runs_the_nccl_branches():
+    """First in this file: its child is spawned before this process has touched the GPU."""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.is_initialized():
+        pytest.skip("this process has already initialised the GPU; run tests/test_00_dist_gpu.py first (it sorts first)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    r = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    assert "nccl" in r["backend"] and r["world"] == 1
+    assert r["total"]["record_device"] == "cuda:0" and "nccl" in r["total"]["backend"]  # the record was a device tensor
+    assert r["by_hand_device"] == "cuda:0" and r["by_hand"] == [r["st"]["episodes"], r["st"]["env_steps"]]
+    assert len(r["per_rank"]) == 1 and r["per_rank"][0] == {k: r["st"][k] for k in ("episodes", "ep_len_sum", "ep_return_sum", "env_steps")}
+    assert r["st"]["env_steps"] == 32 * 4096 and r["st"]["episodes"] > 1000 and r["st"]["errors"] == 0
+    assert not torch.cuda.is_initialized()  # (the two-process test below still finds this process untouched)
+    print("RCCL version", r["nccl_version"])
+
+
 def test_two_processes_shard_the_hip_env_and_gather_stats():
     import torch
     import torch.multiprocessing as mp

@@ -78,11 +78,12 @@ def test_golden_tape(name):
     env.close()
 
 
-def _run_vs_oracle(num_envs, dim, n_snakes, n_fruits, rules, steps, seed, env_id_base=0, greedy=0.0):
-    """Same seeded action stream into the HIP env and the oracle; everything must match."""
+def _run_vs_oracle(num_envs, dim, n_snakes, n_fruits, rules, steps, seed, env_id_base=0, greedy=0.0, **tuning):
+    """Same seeded action stream into the HIP env and the oracle; everything must match.
+    `tuning`: msnake_config's launch-tuning fields (envs_per_block, record_policy, obs_store_policy)."""
     from oracle.snake_oracle import Oracle
     env = _mk(num_envs=num_envs, dim=dim, n_snakes=n_snakes, n_fruits=n_fruits, rules=rules, seed=seed,
-              env_id_base=env_id_base)
+              env_id_base=env_id_base, **tuning)
     ora = Oracle(num_envs, dim=dim, n_snakes=n_snakes, n_fruits=n_fruits, rules=rules, seed=seed,
                  env_id_base=env_id_base)
     assert np.array_equal(env.reset(), ora.reset())
@@ -130,10 +131,9 @@ def test_large_boards_respawn_cell_split(rules, dim, ns, nf):
     assert _run_vs_oracle(n, dim, ns, nf, rules, 160, seed=dim, greedy=0.7) >= 0
 
 
-def test_config3_with_plain_observation_stores(monkeypatch):
+def test_config3_with_plain_observation_stores():
     """4 096 envs stream their observation stores by default; batches of 64-130 MiB use plain ones."""
-    monkeypatch.setenv("MSNAKE_NT", "0")
-    assert _run_vs_oracle(4096, 19, 3, 3, "snake_env", 60, seed=5) > 300
+    assert _run_vs_oracle(4096, 19, 3, 3, "snake_env", 60, seed=5, obs_store_policy="plain") > 300
 
 
 def test_config5_shape_19x19_2snakes_long_lived():
@@ -154,15 +154,15 @@ def test_new_world_4096_envs():
 
 @pytest.mark.parametrize("stores", ["plain", "streaming"])
 @pytest.mark.parametrize("num_envs", [1, 2, 5, 17, 63, 130])
-def test_ragged_batch_sizes_and_unaligned_images(num_envs, stores, monkeypatch):
+def test_ragged_batch_sizes_and_unaligned_images(num_envs, stores):
     """3969-byte images are not 16-byte multiples: every misalignment 0..15 of the per-env image
     and the byte-store edges are exercised; guard bytes around the tensor must stay untouched.
     Both copy-out variants (plain and nt/streaming stores; the library picks one by batch size,
-    MSNAKE_NT forces it at create time) must produce the same bytes."""
+    msnake_config.obs_store_policy forces it) must produce the same bytes."""
     import torch
     from oracle.snake_oracle import Oracle
-    monkeypatch.setenv("MSNAKE_NT", "1" if stores == "streaming" else "0")
-    env = _mk(num_envs=num_envs, dim=19, n_snakes=3, rules="snake_env", seed=9)
+    env = _mk(num_envs=num_envs, dim=19, n_snakes=3, rules="snake_env", seed=9,
+              obs_store_policy="stream" if stores == "streaming" else "plain")
     ora = Oracle(num_envs, dim=19, n_snakes=3, rules="snake_env", seed=9)
     H, W, C = env.obs_shape
     nbytes = num_envs * H * W * C
@@ -626,14 +626,13 @@ def test_large_batches_other_rule_sets(rules, ns, nf):
     _run_vs_oracle(20000, 10, ns, nf, rules, 30, seed=14)
 
 
-@pytest.mark.parametrize("short_rec", ["0", "1"])
-def test_record_policy_is_invisible(short_rec, monkeypatch):
+@pytest.mark.parametrize("policy", ["full", "short"])
+def test_record_policy_is_invisible(policy):
     """snake_env / adversarial steps run on the full 256-byte record (Philox draws parked in its upper
-    half) or on its first 128 bytes; the library picks by batch size, MSNAKE_SHORT_REC forces it."""
-    monkeypatch.setenv("MSNAKE_SHORT_REC", short_rec)
-    assert _run_vs_oracle(3000, 19, 3, 3, "snake_env", 120, seed=15) > 1000
-    _run_vs_oracle(1500, 10, 3, 3, "adversarial", 150, seed=16, greedy=0.5)
-    _run_vs_oracle(700, 6, 3, 3, "snake_env", 120, seed=17, greedy=0.3)
+    half) or on its first 128 bytes; the library picks by batch size, msnake_config.record_policy forces it."""
+    assert _run_vs_oracle(3000, 19, 3, 3, "snake_env", 120, seed=15, record_policy=policy) > 1000
+    _run_vs_oracle(1500, 10, 3, 3, "adversarial", 150, seed=16, greedy=0.5, record_policy=policy)
+    _run_vs_oracle(700, 6, 3, 3, "snake_env", 120, seed=17, greedy=0.3, record_policy=policy, envs_per_block=4)
 
 
 def test_config4_selfplay_at_full_size():
@@ -778,3 +777,146 @@ def test_rollout_device_wrapper_equals_single_steps():
         envs[0].rollout_device(tape[:, :10])
     for e in envs:
         e.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 3: kernel-path combinations that had no oracle comparison (persistent tape x short record / 4 envs per
+# workgroup, fused up-scale above 8 192 envs, persistent tape x fused up-scale), the finished flag in the
+# canonical state, launch tuning through msnake_config
+# ---------------------------------------------------------------------------------------------------
+def _tape_vs_oracle_and_steps(num_envs, dim, ns, nf, rules, T, seed, obs_scale=1, chunk=None, **tuning):
+    """rollout_device(tape) -- ONE persistent launch per chunk -- against (a) T step_device launches of a second
+    handle, every output tensor, and (b) the oracle: reward / done / info every step and every observation byte
+    (the oracle's native frame, replicated on the device when obs_scale > 1)."""
+    import torch
+    from oracle.snake_oracle import Oracle
+    kw = dict(num_envs=num_envs, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=seed, obs_scale=obs_scale, **tuning)
+    a, b = _mk(**kw), _mk(**kw)
+    ora = Oracle(num_envs, dim=dim, n_snakes=ns, n_fruits=nf, rules=rules, seed=seed)
+    up = (lambda o: o) if obs_scale == 1 else (lambda o: o.repeat_interleave(obs_scale, 1).repeat_interleave(obs_scale, 2))
+    dev = a.device
+    o0 = torch.from_numpy(ora.reset()).to(dev)
+    assert torch.equal(a.reset_device(), up(o0)) and torch.equal(b.reset_device(), up(o0))
+    rs = np.random.default_rng(seed + 5)
+    acts = rs.integers(0, 5, (T, num_envs, ns)).astype(np.int32)
+    tape = torch.from_numpy(acts).to(dev)
+    chunk = chunk or T
+    n_done = 0
+    for t0 in range(0, T, chunk):
+        obs, rew, done, info = a.rollout_device(tape[t0:t0 + chunk])
+        for j in range(obs.shape[0]):
+            t = t0 + j
+            o, r, d, i = b.step_device(tape[t])
+            assert torch.equal(o, obs[j]) and torch.equal(r, rew[j]) and torch.equal(d, done[j]) and torch.equal(i, info[j]), t
+            o_obs, o_rew, o_done, o_ns, o_er, o_el = ora.step(acts[t], threads=8)
+            assert np.array_equal(rew[j].cpu().numpy(), o_rew) and np.array_equal(done[j].cpu().numpy(), o_done), t
+            ih = info[j].cpu().numpy()
+            assert np.array_equal(ih[:, 2], o_ns) and np.array_equal(ih[:, 1], o_el), t
+            assert np.array_equal(ih[:, 0].copy().view(np.float32), o_er), t
+            assert torch.equal(obs[j], up(torch.from_numpy(o_obs).to(dev))), t
+            n_done += int(o_done.sum())
+        del obs
+    for e in range(0, num_envs, max(1, num_envs // 48)):
+        assert _state(a, e) == _state(b, e) == ora.get_state(e), e
+    sa, sb = a.stats(), b.stats()
+    assert sa == sb and sa["errors"] == 0 and sa["episodes"] == n_done
+    a.close(); b.close()
+    return n_done
+
+
+def test_persistent_tape_on_the_short_record_path_snake_env():
+    """16 384 envs x 19x19x3: above 8 192 envs a handle runs 4 envs per workgroup on the 128-byte record (no parked
+    Philox draws: every respawning / resetting wave evaluates Philox itself, the record's upper half is never
+    written back).  MODE 3 on that shape, against per-step launches and the oracle, resets and respawns included."""
+    assert _tape_vs_oracle_and_steps(16384, 19, 3, 3, "snake_env", 48, seed=81, chunk=24) > 16384
+
+
+def test_persistent_tape_on_the_short_record_path_adversarial():
+    assert _tape_vs_oracle_and_steps(20000, 10, 3, 3, "adversarial", 40, seed=82, chunk=20) > 20000
+
+
+def test_persistent_tape_short_record_forced_small_batch():
+    """The same path at a small batch, forced through msnake_config (record_policy short, 4 envs per workgroup)."""
+    _tape_vs_oracle_and_steps(777, 19, 3, 3, "snake_env", 48, seed=83, record_policy="short", envs_per_block=4)
+    _tape_vs_oracle_and_steps(500, 10, 2, 2, "adversarial", 48, seed=84, record_policy="short", envs_per_block=2)
+
+
+def test_fused_warpframe_large_batch_against_oracle():
+    """obs_scale = 4 at 16 384 envs (4 envs per workgroup, short record, 1 GB of 84x84x9 frames per step): every
+    byte == the oracle's native frame replicated x4 on both axes.  (cv2 parity itself stays unpinned.)"""
+    import torch
+    from oracle.snake_oracle import Oracle
+    n, steps = 16384, 20
+    env = _mk(num_envs=n, dim=19, n_snakes=3, rules="snake_env", seed=85, obs_scale=4)
+    ora = Oracle(n, dim=19, n_snakes=3, rules="snake_env", seed=85)
+    up = lambda o: torch.from_numpy(o).to(env.device).repeat_interleave(4, 1).repeat_interleave(4, 2)
+    assert torch.equal(env.reset_device(), up(ora.reset()))
+    rs = np.random.default_rng(6)
+    for t in range(steps):
+        act = rs.integers(0, 5, (n, 3)).astype(np.int32)
+        obs, rew, done, info = env.step_device(torch.from_numpy(act).to(env.device))
+        o_obs, o_rew, o_done, o_ns, _, _ = ora.step(act, threads=8)
+        assert torch.equal(obs, up(o_obs)), t
+        assert np.array_equal(rew.cpu().numpy(), o_rew) and np.array_equal(done.cpu().numpy(), o_done), t
+        assert np.array_equal(info[:, 2].cpu().numpy(), o_ns), t
+    assert env.stats()["errors"] == 0
+    env.close()
+
+
+def test_persistent_tape_with_fused_warpframe_at_4096_envs():
+    """msnake_rollout_tape x obs_scale 4 at the bench batch size (260 MB of frames per step)."""
+    assert _tape_vs_oracle_and_steps(4096, 19, 3, 3, "snake_env", 12, seed=86, obs_scale=4, chunk=6) > 1000
+    _tape_vs_oracle_and_steps(2048, 10, 1, 1, "snake_env", 12, seed=87, obs_scale=7, chunk=12)
+
+
+@pytest.mark.parametrize("rules,ns,nf", [("snake_env", 2, 2), ("new_world", 2, 3), ("adversarial", 2, 2)])
+def test_finished_flag_survives_a_checkpoint(rules, ns, nf):
+    """auto_reset = 0: an episode that has ended stays "finished" until the caller resets the env, and
+    msnake_get_stats counts it once.  The canonical state carries that bit (word 7, bit 8), so restoring a
+    checkpoint taken after the episode ended -- into the same handle or a fresh one -- does not count it again."""
+    from oracle.snake_oracle import flat_finished
+    n = 64
+    kw = dict(num_envs=n, dim=6, n_snakes=ns, n_fruits=nf, rules=rules, seed=91, auto_reset=False, max_steps=9)
+    a = _mk(**kw)
+    a.reset()
+    rs = np.random.default_rng(3)
+    for _ in range(12):
+        a.step(rs.integers(0, 5, (n, ns)).astype(np.int32))
+    assert a.stats()["episodes"] == n                      # the 9-step cap has ended every episode
+    assert all(flat_finished(a.get_state_words(e)) for e in range(n))
+    blob = a.get_state_all()
+    assert a.blob_info(blob)["version"] == 2 and a.blob_info(blob)["num_envs"] == n
+    a.set_state_all(blob)                                  # roll back into the same handle ...
+    b = _mk(**kw)
+    b.reset()
+    b.set_state_all(blob)                                  # ... and seed a fresh one
+    for e in range(0, n, 5):
+        b.set_state_words(e, a.get_state_words(e))         # the per-env path carries the bit too
+    acts = rs.integers(0, 5, (6, n, ns)).astype(np.int32)
+    for t in range(6):
+        ra, rb = a.step(acts[t]), b.step(acts[t])
+        assert ra[2].all() and rb[2].all()                 # still done, still reported ...
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+    assert a.stats()["episodes"] == n and b.stats()["episodes"] == 0   # ... and not counted again
+    a.reset(); b.reset()
+    assert not any(flat_finished(a.get_state_words(e)) for e in range(n))
+    for _ in range(12):
+        act = rs.integers(0, 5, (n, ns)).astype(np.int32)
+        a.step(act); b.step(act)
+    assert a.stats()["episodes"] == 2 * n and b.stats()["episodes"] == n
+    # a version-1 blob (no finished bit anywhere) is still accepted
+    old = blob.copy()
+    old[4:8] = np.frombuffer(np.uint32(1).tobytes(), np.uint8)
+    b.set_state_all(old)
+    a.close(); b.close()
+
+
+def test_launch_tuning_fields_are_invisible():
+    """msnake_config's ABI-3 tuning fields change the launch shape, never a result: every envs_per_block, both record
+    policies and both store policies give the oracle's bytes (snake_env and adversarial; new_world ignores the record policy)."""
+    for epb in (1, 2, 3, 4, 5, 8):
+        assert _run_vs_oracle(530, 19, 3, 3, "snake_env", 40, seed=95, envs_per_block=epb) > 100
+    _run_vs_oracle(300, 10, 3, 3, "adversarial", 60, seed=96, envs_per_block=2, record_policy="short", obs_store_policy="plain")
+    _run_vs_oracle(300, 10, 3, 5, "new_world", 60, seed=97, envs_per_block=4, record_policy="short", obs_store_policy="stream")
+    with pytest.raises(RuntimeError, match="envs_per_block"):
+        _mk(num_envs=4, dim=10, n_snakes=2, rules="snake_env", envs_per_block=9)

@@ -1,6 +1,7 @@
 """The self-play driver's math against NumPy restatements of ppo_multi_agent.py (CPU, no env)."""
 import numpy as np
 import pandas as pd
+import pytest
 import torch
 
 from msnake import selfplay
@@ -231,3 +232,41 @@ def test_checkpoints_save_load_and_resume(tmp_path):
     d3 = str(tmp_path / "ckpt3")
     selfplay.learn(_FakeEnv(n_snakes=1), save_dir=d3, **dict(kw, total_timesteps=8 * 4 * 2))
     assert "highscore_model.pt" in os.listdir(d3) and not any(f.startswith("opponent") for f in os.listdir(d3))
+
+
+def test_resume_without_save_interval_and_refusal_without_state(tmp_path):
+    """The trainer state is written with EVERY opponent-pool save (not only every --save-interval), so an
+    interrupted `--save DIR --resume` run without a save interval continues instead of silently starting over;
+    and a directory that holds opponent files but no state file is refused rather than overwritten."""
+    import os
+    d = str(tmp_path / "run")
+    kw = dict(nsteps=4, total_timesteps=8 * 4 * 6, nminibatches=2, noptepochs=1, opponent_save_interval=2)
+
+    class Stop(Exception):
+        pass
+
+    def stop_at_5(line):
+        if "nupdates=5" in line:
+            raise Stop
+
+    with pytest.raises(Stop):
+        selfplay.learn(_FakeEnv(), save_dir=d, log_fn=stop_at_5, **kw)   # save_interval = 0
+    ts = torch.load(os.path.join(d, "trainer_state.pt"), weights_only=True)
+    assert ts["update"] == 4 and ts["pools"] == [(3, 3)]                  # pool files 0 (start), 1 (update 2), 2 (update 4)
+    assert {"opponent1_0.pt", "opponent1_1.pt", "opponent1_2.pt"} <= set(os.listdir(d))
+    _, hist = selfplay.learn(_FakeEnv(seed=1), save_dir=d, resume=True, log_fn=None, **kw)
+    assert [h["nupdates"] for h in hist] == [5, 6] and hist[-1]["num_opponents"] == 4
+    # a fresh run writes its state with the very first pool file
+    d2 = str(tmp_path / "run2")
+
+    def stop_at_1(line):
+        raise Stop
+
+    with pytest.raises(Stop):
+        selfplay.learn(_FakeEnv(), save_dir=d2, log_fn=stop_at_1, **kw)
+    assert torch.load(os.path.join(d2, "trainer_state.pt"), weights_only=True)["update"] == 0
+    # opponents but no state: refuse
+    os.remove(os.path.join(d2, "trainer_state.pt"))
+    with pytest.raises(RuntimeError, match="trainer_state"):
+        selfplay.learn(_FakeEnv(), save_dir=d2, resume=True, log_fn=None, **kw)
+    selfplay.learn(_FakeEnv(), save_dir=d2, resume=False, log_fn=None, **dict(kw, total_timesteps=8 * 4))  # starting over is allowed
