@@ -177,7 +177,7 @@ int msnake_create(const msnake_config* cfg_in, msnake_handle* out) {
         free(h);
         return fail(MSNAKE_E_ARG, "obs_scale %d: output rows must be whole dwords", K);
     }
-    p.img_bytes = (p.S * K + 1023) / 1024 * 1024;  // K-fold wide image, whole 1 KiB wave-instructions
+    p.img_bytes = (p.S * K + (K == 1 ? 15 : 0) + 1023) / 1024 * 1024;  // K-fold wide image, whole 1 KiB wave-instructions
     p.rest.seed_lo = (uint32_t)cfg->seed;
     p.rest.seed_hi = (uint32_t)(cfg->seed >> 32);
     p.rest.env_id_base = cfg->env_id_base;
@@ -194,7 +194,8 @@ int msnake_create(const msnake_config* cfg_in, msnake_handle* out) {
 
     const size_t hdr_bytes = (size_t)p.nenv * MSNAKE_HDR_WORDS * 4;
     const size_t body0_bytes = (size_t)p.nenv * p.n_snakes * 64 * 2;
-    const size_t tmpl_bytes = (size_t)p.img_bytes;
+    const int tmpl_copies = K == 1 ? MSNAKE_TMPL_COPIES : 1;
+    const size_t tmpl_bytes = (size_t)p.img_bytes * tmpl_copies;
     const size_t ring_bytes = (size_t)p.nenv * p.n_snakes * p.rest.cap * 2;
     const bool adv = cfg->rules == MSNAKE_RULES_ADVERSARIAL;
     p.fcap = (p.n_snakes + p.n_snakes * (n2 + 2) + 63) / 64 * 64;  // n fruits + every body of one episode
@@ -218,10 +219,11 @@ int msnake_create(const msnake_config* cfg_in, msnake_handle* out) {
     p.stats = static_cast<unsigned long long*>(h->d_stats);
     // background image: black interior, white 1-px wall ring (snake_multiple_test.py:38,52-56)
     std::vector<uint8_t> tmpl(tmpl_bytes, 0);
-    for (int r = 0; r < W; ++r)
-        for (int c = 0; c < W; ++c)
-            if (r == 0 || r == W - 1 || c == 0 || c == W - 1)
-                memset(&tmpl[((size_t)r * W + c) * p.C * K], 255, (size_t)p.C * K);
+    for (int copy = 0; copy < tmpl_copies; ++copy)  // (copy s: the image starts s bytes into its buffer)
+        for (int r = 0; r < W; ++r)
+            for (int c = 0; c < W; ++c)
+                if (r == 0 || r == W - 1 || c == 0 || c == W - 1)
+                    memset(&tmpl[(size_t)copy * p.img_bytes + copy + ((size_t)r * W + c) * p.C * K], 255, (size_t)p.C * K);
     if ((e = hipMemcpy(const_cast<uint8_t*>(p.tmpl), tmpl.data(), tmpl_bytes, hipMemcpyHostToDevice)) != hipSuccess) {
         (void)hipFree(h->d_state); (void)hipFree(h->d_stats);
         free(h);
@@ -250,7 +252,9 @@ int msnake_create(const msnake_config* cfg_in, msnake_handle* out) {
 #ifdef MSNAKE_DBG_STAGES  // diagnostic builds only (tools/stamp_profile.py): never in the shipped library
     if (const char* dbg = getenv("MSNAKE_DBG_STAGE")) p.rest.dbg_stage = (uint32_t)atoi(dbg);
     if (const char* dbg = getenv("MSNAKE_DBG_BUF")) p.rest.dbg_buf = reinterpret_cast<unsigned long long*>(strtoull(dbg, nullptr, 0));
-    if (const char* dbg = getenv("MSNAKE_DBG_SPAN")) {  // base of a caller-owned [MSNAKE_DBG_SPAN_SLOTS][num_envs][4] u64 device buffer
+#endif
+#if defined(MSNAKE_DBG_STAGES) || defined(MSNAKE_SPAN_LIGHT)  // (measurement builds only, like the block above)
+    if (const char* dbg = getenv("MSNAKE_DBG_SPAN")) {  // base of a caller-owned [MSNAKE_DBG_SPAN_SLOTS][num_envs][8] u64 device buffer
         h->dbg_span = reinterpret_cast<unsigned long long*>(strtoull(dbg, nullptr, 0));
         const char* sl = getenv("MSNAKE_DBG_SPAN_SLOTS");
         h->dbg_span_slots = sl ? (uint32_t)atoi(sl) : 1u;
@@ -291,9 +295,9 @@ static int launch(msnake_handle h, int mode, const int32_t* actions, int32_t act
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (obs && p.obs_scale > 1 && ((uintptr_t)obs & 3))  // the fused x4 / x7 copy-out stores dwords
         return fail(MSNAKE_E_ALIGN, "obs_dev must be 4-byte aligned when obs_scale > 1");
-#ifdef MSNAKE_DBG_STAGES
+#if defined(MSNAKE_DBG_STAGES) || defined(MSNAKE_SPAN_LIGHT)
     if (h->dbg_span && mode == 0)  // every msnake_step launch stamps into its own slot (they wrap)
-        p.rest.dbg_span = h->dbg_span + (size_t)(h->dbg_launch++ % h->dbg_span_slots) * (size_t)p.nenv * 4;
+        p.rest.dbg_span = h->dbg_span + (size_t)(h->dbg_launch++ % h->dbg_span_slots) * (size_t)p.nenv * 8;
 #endif
     hipError_t e = msnake::launch_step(p, h->cfg.rules, mode, h->epb, s);
     if (e != hipSuccess) return fail(MSNAKE_E_HIP, "kernel launch failed: %s", hipGetErrorString(e));

@@ -52,6 +52,10 @@
 #define HDR_PC_FIRST 37
 #define HDR_PC_N 27
 
+// native-size handles keep 16 pre-shifted copies of the background image (copy s: the image starts s bytes into its
+// buffer), for the aligned copy-out of the step kernel; fused x4 / x7 handles keep one
+#define MSNAKE_TMPL_COPIES 16
+
 #define MSNAKE_NO_CELL 0xFFFFu  // never equals a real cell (rows/cols <= 63)
 
 namespace msnake {
@@ -67,8 +71,8 @@ struct StepRest {
     int32_t max_steps;
     uint32_t dbg_stage;          // timing-only early exits (MSNAKE_DBG_STAGES builds)
     unsigned long long* dbg_buf; // MSNAKE_DBG_STAGES builds: [nenv][8] s_memrealtime stamps (MSNAKE_DBG_BUF)
-    unsigned long long* dbg_span; // MSNAKE_DBG_STAGES builds: this launch's [nenv][4] stamps: wave start, stores issued,
-                                  // stores acknowledged (MSNAKE_DBG_SPAN = base of [slots][nenv][4], one slot per launch)
+    unsigned long long* dbg_span; // MSNAKE_DBG_STAGES builds: this launch's [nenv][8] wave stamps (see SPAN in the kernel;
+                                  // MSNAKE_DBG_SPAN = base of [slots][nenv][8], one slot per launch)
     int32_t n_steps;             // MODE 3 (msnake_rollout_tape): steps per launch
     uint64_t obs_step_stride;    // MODE 3: bytes between consecutive steps' observations (0 = overwrite)
     uint64_t scalar_step_stride; // MODE 3: elements between consecutive steps' rew/done/info

@@ -269,6 +269,14 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     constexpr int FR0 = RULES == MSNAKE_RULES_NEW_WORLD ? HDR_FRUIT0_N : HDR_FRUIT0_S;
     // the persistent tape kernel keeps a pristine copy of the background in LDS (native size only)
     constexpr bool LDSBG = MODE == 3 && K == 1;
+    // Aligned copy-out (native size, per-step launches, plain stores -- the batches whose observations fit the Infinity
+    // Cache): the image is composed `shift` = (address of the env's observation) & 15 bytes into its LDS buffer, over
+    // background number `shift` of the 16 pre-shifted ones, so that both sides of every 16-byte chunk of the copy-out
+    // are 16-byte aligned and every wave instruction stores whole 128-byte lines.  Streaming (nt) launches keep the
+    // image at offset 0 and byte-aligned stores: their partly written sectors are what makes nt stores leave the L2
+    // early (whole-line stores stay, nt or not, and the state loads of later waves queue behind their eviction).
+    constexpr int TMPL_COPIES = K == 1 ? MSNAKE_TMPL_COPIES : 1;
+    constexpr bool CAN_ALIGN = K == 1 && MODE != 3;
     auto unpack = [&]() {
         dim = (int)(pk0v & 63u); nf = (int)((pk0v >> 6) & 63u); action_stride = (int)((pk0v >> 12) & 7u);
         auto_reset = (pk0v >> 15) & 1u;
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     auto lds_layout = [&]() {
         // LDS image: W rows of W*K pixels (already replicated horizontally when K > 1), padded to
         // whole 1 KiB wave-instructions
-        img_bytes = (S * K + 1023) & ~1023;
+        img_bytes = (S * K + (K == 1 ? 15 : 0) + 1023) & ~1023;  // (native size: + room for the image's shift, see OBS_SHIFT)
         occ_bytes = (n2 + 15) & ~15;
         img = smem + (size_t)wave * (size_t)(img_bytes + occ_bytes + (LDSBG ? img_bytes : 0));  // observation being composed
         occ = img + img_bytes;                                        // respawn occupancy
@@ -298,10 +306,6 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #define STAMP_FLAG(v) if (p.dbg_buf && lane == 0) p.dbg_buf[(size_t)e * 8 + 7] = (v)
 // second row of stamps per env (rows nenv .. 2*nenv-1 of the buffer): inside the respawn path
 #define STAMP2(k) if (p.dbg_buf && lane == 0) p.dbg_buf[((size_t)nenv + (size_t)e) * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
-// span stamps (tools/span_gap.py): one row of 4 per env and LAUNCH (the glue hands every launch its own slot), so that
-// back-to-back launches can be told apart: [0] the wave has started, [1] it has issued its last store, [2] every store
-// of the wave has been acknowledged (it waits for them: only when the span buffer is set)
-#define SPAN(k) if (p.dbg_span && lane == 0) p.dbg_span[(size_t)e * 4 + (k)] = __builtin_amdgcn_s_memrealtime()
 #define DBG_FEWER_STORES(i) && !((dbg & 0x200) && (i) > 0)  /* stage bit 9: timing with a quarter of the observation stores */
 #define DBG_NO_OBS_STORES(S) ((dbg & 0x400) ? 0 : (S))     /* bit 10: ... with none of them */
 #else
@@ -311,7 +315,25 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #define STAMP2(k)
 #define STAMP(k)
 #define STAMP_FLAG(v)
+#endif
+// span stamps (tools/span_gap.py; -DMSNAKE_DBG_STAGES, or -DMSNAKE_SPAN_LIGHT = the production kernel plus ONLY these):
+// one row of 8 per env and LAUNCH (the glue hands every launch its own slot), so that back-to-back launches can be told
+// apart: [0] the wave has started, [1] its loads have landed, [2] logic done (reward / done / info stored), [3] image
+// painted, [4] last store issued, [5] every store of the wave acknowledged (it waits for them: only when the span buffer
+// is set), [6] flags: 1 a snake ate, 2 episode ended, 4 Philox evaluated, 8 ... behind the stores, XCC id << 8.
+// MSNAKE_SPAN_LIGHT keeps [0], [5] and [6] only.
+#if defined(MSNAKE_DBG_STAGES) || defined(MSNAKE_SPAN_LIGHT)
+#define MSNAKE_HAVE_SPAN 1
+#ifdef MSNAKE_SPAN_LIGHT
+#define SPAN(k) if (((k) == 0 || (k) == 5) && p.dbg_span && lane == 0) p.dbg_span[(size_t)e * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define SPAN(k) if (p.dbg_span && lane == 0) p.dbg_span[(size_t)e * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
+#endif
+#define SPAN_FLAG(v) dbgf |= (v)
+    uint32_t dbgf = 0;
+#else
 #define SPAN(k)
+#define SPAN_FLAG(v)
 #endif
     // Section boundary for the register allocator: lane masks (`lane == k`, `lane < k`: an SGPR pair
     // each) computed before it are not kept alive past it.  Only in the instantiations whose peak
@@ -338,7 +360,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     auto ring_of = [&](int s) -> uint16_t* {
         uint32_t ee = (uint32_t)e;
         asm volatile("" : "+s"(ee));
-        return reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl_of()) + img_bytes) + ((size_t)ee * NS + (size_t)s) * (size_t)cap;
+        return reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl_of()) + img_bytes * TMPL_COPIES) + ((size_t)ee * NS + (size_t)s) * (size_t)cap;
     };
     // THE env record: lane l holds word l; lanes FR0+f hold fruit f.  Short record: lanes 32..63 re-read
     // words 0..31 (the same cache line: no extra traffic, no exec-mask juggling) and are zeroed
@@ -363,12 +385,12 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     auto fl0_of = [&]() -> uint16_t* {
         uint32_t ee = (uint32_t)e;
         asm volatile("" : "+s"(ee));
-        return reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl_of()) + img_bytes) + (size_t)nenv * NS * cap + (size_t)ee * 64;
+        return reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl_of()) + img_bytes * TMPL_COPIES) + (size_t)nenv * NS * cap + (size_t)ee * 64;
     };
     auto flist_of = [&]() -> uint16_t* {
         uint32_t ee = (uint32_t)e;
         asm volatile("" : "+s"(ee));
-        return reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl_of()) + img_bytes) + (size_t)nenv * NS * cap + (size_t)nenv * 64 +
+        return reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(tmpl_of()) + img_bytes * TMPL_COPIES) + (size_t)nenv * NS * cap + (size_t)nenv * 64 +
                (size_t)ee * fcap;
     };
     uint32_t fr = 0;
@@ -384,6 +406,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     constexpr bool PCACHE = RULES != MSNAKE_RULES_NEW_WORLD;  // new_world's fruits may fill the record
     uint32_t draws = 0, draw_base = 0, draws_n = 0;
     bool refilled = false;
+    uint32_t slow_step = 0;  // != 0: this wave respawned a fruit or ended an episode in this launch (MODE 0 / 1)
     // words 32..63 of a snake_env record only hold the Philox cache: they go back to memory in the launches
     // that change it (a Philox evaluation, the 2^32-draw wrap), not in every one.  (new_world keeps its fruits
     // there; the adversarial kernels have no SGPR to spare for the flag.)
@@ -399,6 +422,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         asm volatile("" : "+s"(k0), "+s"(k1));
         draws = philox_draws(ctr_lo, ctr_hi, lane, (uint32_t)gid, (uint32_t)(gid >> 32), k0, k1);
         draw_base = ctr_lo; draws_n = 64; refilled = true;
+        SPAN_FLAG(4u);
     };
     // the next `need` (<= 64) draws are cached afterwards.  Callers run this BEFORE they build
     // their wide temporaries (free-cell masks), so Philox does not set the kernel's VGPR peak.
@@ -638,6 +662,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 abatch = (uint32_t)actions[((size_t)t * (size_t)nenv + (size_t)e) * action_stride + (lane & 3)];
         }
     }
+    // aligned copy-out: where in its LDS buffer the image starts (0 for streaming launches, see CAN_ALIGN)
+    const uint32_t obs_shift = (CAN_ALIGN && obs_t && !(pk2 & PK2_STREAM_OBS)) ? ((uint32_t)(uintptr_t)(obs_t + (size_t)e * S) & 15u) : 0u;
     // background image (black interior, white wall ring): one L1/L2-resident copy shared by every
     // wave, a whole number of 1 KiB wave-instructions so that no lane needs a predicate.
     // (Storing the background to HBM right here, ahead of the logic, was measured and is SLOWER:
@@ -652,6 +678,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     if (obs_t && (!LDSBG || step_i == 0)) {
 #endif
         const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl_of()) + lane;
+        if (CAN_ALIGN) tsrc += obs_shift * (uint32_t)(img_bytes >> 4);  // background number `shift`: the image starts `shift` bytes into it
         uint8_t* dst = LDSBG ? bg : img;
         const int nk = img_bytes >> 10;
 #define MSNAKE_GP(k) ((const __attribute__((address_space(1))) void*)(tsrc + (k) * 64))
@@ -722,6 +749,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         uint32_t v_em = 0;  // bit f: fruit f lies on this snake's new head
         bool any_eat = false;
         STAMP(1);
+        SPAN(1);
         if (RULES == MSNAKE_RULES_ADVERSARIAL) {  // list based
 #pragma unroll
             for (int s = 0; s < NS; ++s)
@@ -1088,6 +1116,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         if (dbg & 0x1000) done = 0;
 #endif
         asm volatile("" : "+s"(done));  // (keeps it one SGPR: as a predicate it becomes a lane mask, a select and a compare)
+        slow_step = done | (any_eat ? 1u : 0u);
         if (done) {
             out_ret = ep_ret; out_len = ep_len;
             // logging totals stay in the env record (summed by msnake_get_stats): same-address
@@ -1113,6 +1142,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         STAMP(4);
         DBG_EXIT(5)
         STAMP_FLAG((unsigned long long)(any_eat ? 1 : 0) | (done ? 2ull : 0ull));
+        SPAN_FLAG((any_eat ? 1u : 0u) | (done ? 2u : 0u));
+        SPAN(2);
         if (lane == 0) {
             rew_t[e] = reward;
             done_t[e] = (uint8_t)done;
@@ -1131,7 +1162,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         __builtin_amdgcn_s_setprio(MSNAKE_PRIO_PAINT);
 #endif
         wave_sync();
-        uint8_t* px = img;
+        uint8_t* px = img + (CAN_ALIGN ? obs_shift : 0u);
         // fruits first ([S]:43-44): red in every view; the background is already black
         if (RULES == MSNAKE_RULES_ADVERSARIAL) {
             // list entries outside the grid (dead out-of-grid heads) would land on the wall ring,
@@ -1183,10 +1214,34 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
         wave_sync();
         STAMP(5);
+        SPAN(3);
 #ifdef MSNAKE_DBG_STAGES
         if (dbg == 6) asm volatile("s_endpgm");
 #endif
-        if (K == 1) {
+        if (CAN_ALIGN && !(pk2 & PK2_STREAM_OBS)) {
+            // ---- 7a. aligned copy-out (plain stores): LDS byte x of the buffer <-> global byte g_al + x, both sides 16-byte
+            //          aligned; wave instruction i covers the i-th KiB counted from the 128-byte line the image starts
+            //          in, so every store instruction writes whole lines (1.00 x the image in WRITE_SIZE; the byte-aligned
+            //          stores below write the sectors at their instruction boundaries twice: 1.07 x).  The <= 15 bytes in
+            //          front of the first whole chunk and behind the last one go singly.
+            //          Measured (round 3, same box): 23.2-23.7 vs 24.9-26.2 us at 32 768 envs, 13.96 vs 15.21 at 16 384.
+            uint8_t* obs_env = obs_t + (size_t)e * S;
+            uint8_t* g_al = obs_env - obs_shift;
+            const int lead = (int)(((uint32_t)(uintptr_t)g_al >> 4) & 7u);  // chunks between the start of the 128-byte line and g_al
+            const int end = (int)obs_shift + DBG_NO_OBS_STORES(S);           // the image = buffer bytes [shift, end)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = 64 * i + lane - lead;
+                if (k >= 0 && 16 * k >= (int)obs_shift && 16 * k + 16 <= end DBG_FEWER_STORES(i))
+                    *reinterpret_cast<uint4*>(g_al + 16 * k) = *reinterpret_cast<const uint4*>(img + 16 * k);
+            }
+            for (int k = 256 + lane - lead; 16 * k + 16 <= end; k += 64)     // (images beyond 4 KiB)
+                *reinterpret_cast<uint4*>(g_al + 16 * k) = *reinterpret_cast<const uint4*>(img + 16 * k);
+            // head bytes [shift, 16) on lanes 0..15 (when shift > 0), tail bytes [end & ~15, end) on lanes 16..31
+            const int byte = lane < 16 ? lane : (end & ~15) + (lane - 16);
+            const bool on = lane < 16 ? (obs_shift != 0 && lane >= (int)obs_shift && lane < end) : (lane < 32 && byte < end && byte >= 16);
+            if (on) g_al[byte] = img[byte];
+        } else if (K == 1) {
             // ---- 7. LDS image -> HBM: 16 bytes per lane, 1 KiB contiguous per wave instruction.
             //         The 3969-byte images are not 16-byte multiples, so the global side is
             //         byte-aligned (the hardware splits the few lines that straddle); the last
@@ -1234,14 +1289,12 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             uint32_t* out = reinterpret_cast<uint32_t*>(obs_t + (size_t)e * S * (K * K));
             const uint32_t* src = reinterpret_cast<const uint32_t*>(img);
             const int rowdw = (W * K * C) >> 2;
-            if (MODE != 3 && (pk2 & PK2_STREAM_OBS)) {
-                for (int r = 0; r < W; ++r)
-                    for (int q = lane; q < rowdw; q += 64) {
-                        const uint32_t v = src[r * rowdw + q];
-#pragma unroll
-                        for (int rr = 0; rr < K; ++rr) __builtin_nontemporal_store(v, &out[(size_t)(r * K + rr) * rowdw + q]);
-                    }
-            } else {
+            // (Round 3, measured and rejected: the contiguous 63 504-byte frame written as 16-byte-per-lane stores, every
+            //  wave instruction covering whole 128-byte lines -- rows are dword-, not 16-byte multiples, so chunks are
+            //  re-cut across rows -- with plain or nt stores: 40.0 / 40.8 vs 38.2 us at 4 096 envs, 399.6 / 416.3 vs
+            //  404.7 us at 32 768.  A logic-free kernel storing 62 KiB per wave reaches 5.4-5.65 TB/s on this chip
+            //  (tools/probes/write_bw_probe.hip); these 2 GB launches run at 5.2: the store stream is at its roofline.)
+            {
                 for (int r = 0; r < W; ++r)
                     for (int q = lane; q < rowdw; q += 64) {
                         const uint32_t v = src[r * rowdw + q];
@@ -1256,22 +1309,23 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 
     // ---- 5. state write-back (once per launch): the record; the body rings went out slot by slot --
     if (MODE != 2) {
-#ifndef MSNAKE_NO_LATE_REFILL
-        if (PCACHE && !short_rec) {
-            // Late refill: Philox runs HERE, behind the wave's observation stores (its evaluation overlaps their
-            // latency), whenever the draws parked in the record could no longer cover everything ONE step can ask for
-            // -- NS respawns ([S]: every fruit is eaten at most once per step) and the 4*NS draws of a reset --, so
-            // that no respawning or resetting wave evaluates Philox ahead of its logic in a later launch.
-            // (ensure_draws still does, should a step ever need more: [A] steps that respawn many list fruits.)
-            constexpr uint32_t LOW_WATER = 5u * NS;
+#ifdef MSNAKE_LATE_REFILL
+        // Refill the parked Philox draws BEHIND the wave's observation stores, by the waves that have time for it: a wave
+        // that stayed on the fast path in this launch (no respawn, no episode end: 94 % of them, and they finish ~1 us
+        // ahead of the launch's last waves) tops the cache up once MSNAKE_LATE_REFILL draws (default build: off) are used,
+        // so that a later respawn or reset finds its draws parked instead of evaluating Philox ahead of its logic.
+        // MSNAKE_LATE_REFILL = 0: every wave refills once fewer than 5*NS draws remain (measured: slower).
+        if (PCACHE && !short_rec && MODE != 3) {
             const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO);
             bool late;
             if (refilled)  // Philox already ran (ahead of some logic): again only if what it left cannot fill the parking words
                 late = !(draws_n == 64 && ctr_lo - draw_base + HDR_PC_N <= 64u);
+            else if (MSNAKE_LATE_REFILL == 0)
+                late = rdlane(hv, HDR_PC_VALID) != 1u || ctr_lo - rdlane(hv, HDR_PC_BASE) > HDR_PC_N - 5u * NS;  // (mod 2^32, like ensure_draws)
             else
-                late = rdlane(hv, HDR_PC_VALID) != 1u || ctr_lo - rdlane(hv, HDR_PC_BASE) > HDR_PC_N - LOW_WATER;  // (mod 2^32, like ensure_draws)
+                late = slow_step == 0 && (rdlane(hv, HDR_PC_VALID) != 1u || ctr_lo - rdlane(hv, HDR_PC_BASE) >= (uint32_t)(MSNAKE_LATE_REFILL));
             if (late) {
-                __builtin_amdgcn_s_setprio(3);
+                SPAN_FLAG(8u);
                 refill_draws(ctr_lo, rdlane(hv, HDR_CTR_HI));
             }
         }
@@ -1297,11 +1351,14 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
         if (RULES == MSNAKE_RULES_ADVERSARIAL && fr_dirty) fl0_of()[lane] = (uint16_t)fr;
     }
-#ifdef MSNAKE_DBG_STAGES
+#ifdef MSNAKE_HAVE_SPAN
     if (p.dbg_span) {
-        SPAN(1);
+        SPAN(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        SPAN(2);
+        SPAN(5);
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (lane == 0) p.dbg_span[(size_t)e * 8 + 6] = dbgf | ((xcc & 15u) << 8);
     }
 #endif
 }
@@ -1558,8 +1615,9 @@ static hipError_t launch_k(const StepParams& p, int mode, int epb, hipStream_t s
         if (lds_wave > 64 * 1024) return hipErrorInvalidValue;
     }
     const size_t lds = lds_wave * (size_t)epb;
-    const uint32_t pk2 = (p.short_rec ? PK2_SHORT_REC : 0u) | (p.rest.stream_obs ? PK2_STREAM_OBS : 0u) |
-                         (p.stream_tape ? PK2_STREAM_TAPE : 0u) | ((uint32_t)epb << PK2_EPB_SHIFT) |
+    // (the dword stores of the fused x4 / x7 copy-out never stream: 256 B per wave instruction, 2.5x slower with nt)
+    const uint32_t pk2 = (p.short_rec ? PK2_SHORT_REC : 0u) | (p.rest.stream_obs && K == 1 ? PK2_STREAM_OBS : 0u) |
+                         (p.stream_tape && K == 1 ? PK2_STREAM_TAPE : 0u) | ((uint32_t)epb << PK2_EPB_SHIFT) |
                          (div_magic((uint32_t)p.dim) << PK2_DIVM_SHIFT);
     const dim3 grid((unsigned)((((p.nenv + epb - 1) / epb) + 63) & ~63));  // whole groups of 64: see the kernel's XCD swap
     const dim3 block(64u * (unsigned)epb);

@@ -920,3 +920,31 @@ def test_launch_tuning_fields_are_invisible():
     _run_vs_oracle(300, 10, 3, 5, "new_world", 60, seed=97, envs_per_block=4, record_policy="short", obs_store_policy="stream")
     with pytest.raises(RuntimeError, match="envs_per_block"):
         _mk(num_envs=4, dim=10, n_snakes=2, rules="snake_env", envs_per_block=9)
+
+
+@pytest.mark.parametrize("lead", [0, 4, 8, 16, 48])
+def test_fused_warpframe_copy_out_variants(lead):
+    """The fused copy-out writes 16 bytes per lane over the contiguous 84x84 frames when they are 16-byte aligned
+    (whole 128-byte lines per wave instruction; the first line of a frame starts anywhere in it: lead 16 / 48) and
+    falls back to dword stores when the caller's buffer is only 4-byte aligned (lead 4 / 8).  Same bytes either way,
+    guard bytes untouched."""
+    import torch
+    from oracle.snake_oracle import Oracle
+    n = 70
+    env = _mk(num_envs=n, dim=19, n_snakes=3, rules="snake_env", seed=44, obs_scale=4)
+    ora = Oracle(n, dim=19, n_snakes=3, rules="snake_env", seed=44)
+    H, W, C = env.obs_shape
+    nbytes = n * H * W * C
+    buf = torch.full((nbytes + 256,), 0xAB, dtype=torch.uint8, device=env.device)
+    assert buf.data_ptr() % 256 == 0
+    out = buf[lead:lead + nbytes].view(n, H, W, C)
+    up = lambda o: np.repeat(np.repeat(o, 4, axis=1), 4, axis=2)
+    assert np.array_equal(env.reset_device(out=out).cpu().numpy(), up(ora.reset()))
+    rs = np.random.default_rng(lead)
+    for t in range(25):
+        act = rs.integers(0, 5, (n, 3)).astype(np.int32)
+        obs, _, _, _ = env.step_device(torch.from_numpy(act).to(env.device), out=out)
+        assert np.array_equal(obs.cpu().numpy(), up(ora.step(act)[0])), t
+    host = buf.cpu().numpy()
+    assert (host[:lead] == 0xAB).all() and (host[lead + nbytes:] == 0xAB).all()
+    env.close()

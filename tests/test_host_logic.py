@@ -84,7 +84,7 @@ def test_create_argument_checks_before_touching_the_gpu():
 def test_shipped_library_reads_no_environment_knobs():
     """Launch tuning is part of msnake_config (ABI 3); getenv exists only in the -DMSNAKE_DBG_STAGES block."""
     src = open(os.path.join(ROOT, "self-play-on-multi-snakes-environment_amd", "csrc", "msnake_capi.hip")).read()
-    outside = re.sub(r"#ifdef MSNAKE_DBG_STAGES.*?#endif", "", src, flags=re.S)
+    outside = re.sub(r"#if(def MSNAKE_DBG_STAGES|\s+defined\(MSNAKE_DBG_STAGES\) \|\| defined\(MSNAKE_SPAN_LIGHT\)).*?#endif", "", src, flags=re.S)
     assert "getenv" not in outside
     assert "getenv" not in open(os.path.join(ROOT, "self-play-on-multi-snakes-environment_amd", "csrc", "msnake_kernels.hip")).read()
 

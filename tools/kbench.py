@@ -17,13 +17,17 @@ def main():
     ap.add_argument("--rules", default="snake_env")
     ap.add_argument("--iters", type=int, default=300)
     ap.add_argument("--scale", type=int, default=1)
+    ap.add_argument("--store-policy", default="auto", choices=["auto", "plain", "stream"])
+    ap.add_argument("--record-policy", default="auto", choices=["auto", "full", "short"])
+    ap.add_argument("--epb", type=int, default=0)
     args = ap.parse_args()
     import torch
     import msnake
 
     dev = torch.device("cuda", 0)
     for n in args.envs:
-        env = msnake.MultiSnakeVecEnv(n, dim=args.dim, n_snakes=args.snakes, rules=args.rules, seed=0, device=dev, obs_scale=args.scale)
+        env = msnake.MultiSnakeVecEnv(n, dim=args.dim, n_snakes=args.snakes, rules=args.rules, seed=0, device=dev, obs_scale=args.scale,
+                                       obs_store_policy=args.store_policy, record_policy=args.record_policy, envs_per_block=args.epb)
         env.reset_device()
         T = 64
         tape = torch.randint(0, 5, (T, n, args.snakes), dtype=torch.int32, device=dev)

@@ -19,12 +19,12 @@ import torch
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-span = torch.zeros((K, n, 4), dtype=torch.int64, device="cuda")
+span = torch.zeros((K, n, 8), dtype=torch.int64, device="cuda")
 os.environ["MSNAKE_DBG_SPAN"] = hex(span.data_ptr())
 os.environ["MSNAKE_DBG_SPAN_SLOTS"] = str(K)
 import msnake
 
-assert "dbg" in os.path.basename(msnake._capi.LIB_PATH), "needs the diagnostic build: MSNAKE_LIB=.../libmsnake_dbg.so"
+assert any(k in os.path.basename(msnake._capi.LIB_PATH) for k in ("dbg", "span")), "needs a measurement build: MSNAKE_LIB=.../libmsnake_dbg.so or libmsnake_span.so"
 env = msnake.MultiSnakeVecEnv(n, dim=19, n_snakes=3, seed=0)
 env.reset_device()
 T = 256
@@ -56,25 +56,56 @@ for rep in range(5):
     torch.cuda.synchronize()
     ev_us = e0.elapsed_time(e1) * 1e3 / K
     s = span.cpu().numpy()
-    start, issued, acked = s[:, :, 0], s[:, :, 1], s[:, :, 2]
+    start, loads, logic, painted, issued, acked, flags = (s[:, :, i] for i in range(7))
+    light = bool((issued == 0).all())  # -DMSNAKE_SPAN_LIGHT: the production kernel with the start / acknowledged stamps only
+    if light:
+        loads = logic = painted = start
+        issued = acked
     assert (start > 0).all() and (acked >= issued).all()
     first, last_start = start.min(1), start.max(1)
     end_issue, end_ack = issued.max(1), acked.max(1)
     spans = (end_ack - first) / 100.0
     gaps = (first[1:] - end_ack[:-1]) / 100.0
     cad = (first[1:] - first[:-1]) / 100.0
+    life = (acked - start) / 100.0
+    rel_end = (acked - first[:, None]) / 100.0          # when a wave ended, since its launch's first wave started
+    stage = lambda a, b: round(float(np.median((b - a) / 100.0)), 3)
+    pct = lambda x, q: round(float(np.percentile(x, q)), 3)
+    # the waves that end a launch: its last 32 finishers
+    order = np.argsort(acked, axis=1)[:, -32:]
+    take = lambda a: np.take_along_axis(a, order, axis=1)
+    tf = take(flags)
+    tail = {"start_offset_us": round(float(np.median((take(start) - first[:, None]) / 100.0)), 3),
+            "life_us": round(float(np.median(take(life))), 3),
+            "loads_us": stage(take(start), take(loads)), "logic_us": stage(take(loads), take(logic)),
+            "paint_us": stage(take(logic), take(painted)), "copy_out_us": stage(take(painted), take(issued)),
+            "ack_us": stage(take(issued), take(acked)),
+            "share_ate": round(float(((tf & 1) != 0).mean()), 3), "share_episode_end": round(float(((tf & 2) != 0).mean()), 3),
+            "share_philox_ahead_of_logic": round(float((((tf & 4) != 0) & ((tf & 8) == 0)).mean()), 3),
+            "share_late_refill": round(float(((tf & 8) != 0).mean()), 3),
+            "share_fast_path": round(float(((tf & 0xF) == 0).mean()), 3)}
+    xcc = (flags >> 8) & 15
+    per_xcd = [round(float(np.median(np.where(xcc == x, rel_end, 0).max(1))), 3) for x in range(8)]
+    cls = lambda m: {"share": round(float(m.mean()), 4), "life_us_median": round(float(np.median(life[m])), 3) if m.any() else None,
+                     "life_us_p90": pct(life[m], 90) if m.any() else None}
     reps.append({
+        "stamps": "start + acknowledged only (stage splits are not measured)" if light else "all",
         "hip_event_us_per_launch": round(ev_us, 3),
         "stamp_cadence_us": round(float((first[-1] - first[0]) / 100.0 / (K - 1)), 3),
-        "span_us": {"median": round(float(np.median(spans)), 3), "p10": round(float(np.percentile(spans, 10)), 3),
-                    "p90": round(float(np.percentile(spans, 90)), 3)},
-        "gap_us": {"median": round(float(np.median(gaps)), 3), "p10": round(float(np.percentile(gaps, 10)), 3),
-                   "p90": round(float(np.percentile(gaps, 90)), 3), "negative_share": round(float((gaps < 0).mean()), 4)},
+        "span_us": {"median": round(float(np.median(spans)), 3), "p10": pct(spans, 10), "p90": pct(spans, 90)},
+        "gap_us": {"median": round(float(np.median(gaps)), 3), "p10": pct(gaps, 10), "p90": pct(gaps, 90),
+                   "negative_share": round(float((gaps < 0).mean()), 4)},
         "cadence_us_median": round(float(np.median(cad)), 3),
         "first_to_last_wave_start_us": round(float(np.median((last_start - first) / 100.0)), 3),
         "first_start_to_last_store_issued_us": round(float(np.median((end_issue - first) / 100.0)), 3),
         "last_store_issued_to_last_ack_us": round(float(np.median((end_ack - end_issue) / 100.0)), 3),
-        "wave_life_us_median": round(float(np.median((acked - start) / 100.0)), 3),
+        "wave_life_us": {"p50": pct(life, 50), "p90": pct(life, 90), "p99": pct(life, 99), "max_median_over_launches": round(float(np.median(life.max(1))), 3)},
+        "wave_stages_us_median": {"loads": stage(start, loads), "logic": stage(loads, logic), "paint": stage(logic, painted),
+                                  "copy_out": stage(painted, issued), "ack": stage(issued, acked)},
+        "by_class": {"fast_path": cls((flags & 0xF) == 0), "ate": cls((flags & 1) != 0), "episode_end": cls((flags & 2) != 0),
+                     "philox_ahead_of_logic": cls(((flags & 4) != 0) & ((flags & 8) == 0)), "late_refill": cls((flags & 8) != 0)},
+        "last_32_finishers_per_launch": tail,
+        "last_ack_per_xcd_us_since_launch_start": per_xcd,
     })
 med = lambda k: statistics.median(r[k] for r in reps)
 out = {"what": __doc__.split("\n")[0], "gpu": torch.cuda.get_device_name(0), "library": os.path.basename(msnake._capi.LIB_PATH),
