@@ -264,7 +264,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     int dim, nf, action_stride, S, cap, W, n2, img_bytes, occ_bytes;
     bool auto_reset, short_rec;
     uint32_t max_steps;
-    uint8_t *img, *occ, *bg;
+    uint8_t *img, *bg;
     // inline fruits: record words FR0 .. FR0 + nf - 1 (lanes of hv)
     constexpr int FR0 = RULES == MSNAKE_RULES_NEW_WORLD ? HDR_FRUIT0_N : HDR_FRUIT0_S;
     // the persistent tape kernel keeps a pristine copy of the background in LDS (native size only)
@@ -292,8 +292,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         img_bytes = (S * K + (K == 1 ? 15 : 0) + 1023) & ~1023;  // (native size: + room for the image's shift, see OBS_SHIFT)
         occ_bytes = (n2 + 15) & ~15;
         img = smem + (size_t)wave * (size_t)(img_bytes + occ_bytes + (LDSBG ? img_bytes : 0));  // observation being composed
-        occ = img + img_bytes;                                        // respawn occupancy
-        bg = occ + occ_bytes;                                         // LDSBG: background, copied to img every step
+        bg = img + img_bytes + occ_bytes;                             // LDSBG: background, copied to img every step (the respawn occupancy sits in between)
     };
     unpack();
 #ifdef MSNAKE_DBG_STAGES
@@ -324,8 +323,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 // MSNAKE_SPAN_LIGHT keeps [0], [5] and [6] only.
 #if defined(MSNAKE_DBG_STAGES) || defined(MSNAKE_SPAN_LIGHT)
 #define MSNAKE_HAVE_SPAN 1
-#ifdef MSNAKE_SPAN_LIGHT
-#define SPAN(k) if (((k) == 0 || (k) == 5) && p.dbg_span && lane == 0) p.dbg_span[(size_t)e * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
+#ifdef MSNAKE_SPAN_LIGHT  // (the start stamp stays in registers until the end: a store ahead of the state loads would sit in their vmcnt wait)
+    unsigned long long span_t0 = 0;
+#define SPAN(k) do { if ((k) == 0) span_t0 = __builtin_amdgcn_s_memrealtime(); \
+                     if ((k) == 5 && p.dbg_span && lane == 0) { p.dbg_span[(size_t)e * 8] = span_t0; p.dbg_span[(size_t)e * 8 + 5] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define SPAN(k) if (p.dbg_span && lane == 0) p.dbg_span[(size_t)e * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
 #endif
@@ -340,6 +341,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // SGPR demand would otherwise spill (adversarial rules, four snakes); a no-op elsewhere.
     constexpr bool FENCED = RULES == MSNAKE_RULES_ADVERSARIAL || NS == 4 || MODE == 3;
 #define LANE_FENCE() do { if (FENCED) asm volatile("" : "+v"(lane)); } while (0)
+    // The same for everything unpacked from the three configuration words (a dozen SGPRs): re-derived behind the fence
+    // from copies the compiler cannot see through, so the values of the section before die there.  (The persistent
+    // kernel does this once per step already.)
+#define CONFIG_FENCE() do { if (FENCED && MODE != 3) { asm volatile("" : "+s"(pk0v), "+s"(pk1v), "+s"(pk2v)); unpack(); lds_layout(); } } while (0)
 
     // ---- 0. every load whose address depends only on the env index.  One allocation holds
     //         [records | chunk-0 bodies | background image | rings]: one preloaded pointer ---------
@@ -512,6 +517,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // moved, i.e. without their popped tail (lane j of bf_pop) and with their new head (bf_nh).
     uint32_t bf_moved = 0, bf_pop = 0, bf_nh = 0;
     auto build_free = [&]() {
+        uint8_t* occ = img + img_bytes;  // respawn occupancy (slow path: derived here, not held across the kernel)
         uint32_t* occw = reinterpret_cast<uint32_t*>(occ);
         for (int i = lane; i < ((n2 + 63) >> 6) * 2; i += 64) occw[i] = 0u;  // one bit per cell
         wave_sync();
@@ -663,7 +669,12 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
     }
     // aligned copy-out: where in its LDS buffer the image starts (0 for streaming launches, see CAN_ALIGN)
-    const uint32_t obs_shift = (CAN_ALIGN && obs_t && !(pk2 & PK2_STREAM_OBS)) ? ((uint32_t)(uintptr_t)(obs_t + (size_t)e * S) & 15u) : 0u;
+    // (derived where it is used -- three scalar instructions -- instead of being held in an SGPR for the whole kernel)
+    auto obs_shift_of = [&]() -> uint32_t {
+        uint32_t ee = (uint32_t)e;
+        if (FENCED) asm volatile("" : "+s"(ee));
+        return (CAN_ALIGN && obs_t && !(pk2 & PK2_STREAM_OBS)) ? (((uint32_t)(uintptr_t)obs_t + ee * (uint32_t)S) & 15u) : 0u;
+    };
     // background image (black interior, white wall ring): one L1/L2-resident copy shared by every
     // wave, a whole number of 1 KiB wave-instructions so that no lane needs a predicate.
     // (Storing the background to HBM right here, ahead of the logic, was measured and is SLOWER:
@@ -678,7 +689,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     if (obs_t && (!LDSBG || step_i == 0)) {
 #endif
         const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl_of()) + lane;
-        if (CAN_ALIGN) tsrc += obs_shift * (uint32_t)(img_bytes >> 4);  // background number `shift`: the image starts `shift` bytes into it
+        if (CAN_ALIGN) tsrc += obs_shift_of() * (uint32_t)(img_bytes >> 4);  // background number `shift`: the image starts `shift` bytes into it
         uint8_t* dst = LDSBG ? bg : img;
         const int nk = img_bytes >> 10;
 #define MSNAKE_GP(k) ((const __attribute__((address_space(1))) void*)(tsrc + (k) * 64))
@@ -946,6 +957,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
 
         LANE_FENCE();
+        CONFIG_FENCE();
         uint32_t hd[NS], ln[NS], hp2[NS], wc[NS];  // head cell, length, overflow head pos, SN_C word
         uint32_t lenor = 0;                        // OR of the SN_A words: some body holds 64+ cells iff >= 64 << 16
 #pragma unroll
@@ -1107,6 +1119,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         DBG_EXIT(4)
         // ---- 4. vec layer: episode statistics and auto reset -----------------------------------
         LANE_FENCE();
+        CONFIG_FENCE();
         float ep_ret = __uint_as_float(rdlane(hv, HDR_EP_RETURN)) + reward;
         uint32_t ep_len = rdlane(hv, HDR_EP_LEN) + 1;
         float out_ret = 0.0f;
@@ -1157,12 +1170,13 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 
     // ---- 6. paint the observation over the background, in reference order ----------------------
     LANE_FENCE();
+    CONFIG_FENCE();
     if (obs_t) {
 #ifdef MSNAKE_PRIO_PAINT
         __builtin_amdgcn_s_setprio(MSNAKE_PRIO_PAINT);
 #endif
         wave_sync();
-        uint8_t* px = img + (CAN_ALIGN ? obs_shift : 0u);
+        uint8_t* px = img + (CAN_ALIGN ? obs_shift_of() : 0u);
         // fruits first ([S]:43-44): red in every view; the background is already black
         if (RULES == MSNAKE_RULES_ADVERSARIAL) {
             // list entries outside the grid (dead out-of-grid heads) would land on the wall ring,
@@ -1226,6 +1240,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             //          front of the first whole chunk and behind the last one go singly.
             //          Measured (round 3, same box): 23.2-23.7 vs 24.9-26.2 us at 32 768 envs, 13.96 vs 15.21 at 16 384.
             uint8_t* obs_env = obs_t + (size_t)e * S;
+            const uint32_t obs_shift = obs_shift_of();
             uint8_t* g_al = obs_env - obs_shift;
             const int lead = (int)(((uint32_t)(uintptr_t)g_al >> 4) & 7u);  // chunks between the start of the 128-byte line and g_al
             const int end = (int)obs_shift + DBG_NO_OBS_STORES(S);           // the image = buffer bytes [shift, end)
@@ -1351,6 +1366,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         }
         if (RULES == MSNAKE_RULES_ADVERSARIAL && fr_dirty) fl0_of()[lane] = (uint16_t)fr;
     }
+#ifdef MSNAKE_END_WAIT  // experiment: every wave stays until its stores have been acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 #ifdef MSNAKE_HAVE_SPAN
     if (p.dbg_span) {
         SPAN(4);
