@@ -189,12 +189,15 @@ def main():
     ap.add_argument("--python-loop", action="store_true", help="issue launches from Python instead of msnake_step_tape")
     ap.add_argument("--no-rollout", action="store_true",
                     help="skip the secondary legs: msnake_rollout_tape, per_step_strided, selfplay_rollout (profiling)")
+    ap.add_argument("--legs", default="tape,strided,selfplay", help="which secondary legs to run (comma list; --no-rollout = none)")
+    ap.add_argument("--obs-scale", type=int, default=1, choices=[1, 4], help="4 = the fused 84x84x9 WarpFrame series (profiling; not the headline workload)")
     ap.add_argument("--epb", type=int, default=0, help="msnake_config.envs_per_block (0 = auto)")
     ap.add_argument("--record-policy", default="auto", choices=["auto", "full", "short"])
     ap.add_argument("--store-policy", default="auto", choices=["auto", "plain", "stream"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + MSNAKE_BENCH_ONE_DEVICE=1 rehearses the N>1 path with every rank on cuda:0")
     args = ap.parse_args()
+    legs = set() if args.no_rollout or args.python_loop else {x for x in args.legs.split(",") if x}
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -228,7 +231,8 @@ def main():
 
     # rank r owns the global env ids [r*n, (r+1)*n): the shipped sharding API, not a hand-rolled one
     env = msnake.make_sharded(n * world, rank, world, device=dev, dim=DIM, n_snakes=N_SNAKES, rules="snake_env", seed=0,
-                              envs_per_block=args.epb, record_policy=args.record_policy, obs_store_policy=args.store_policy)
+                              envs_per_block=args.epb, record_policy=args.record_policy, obs_store_policy=args.store_policy,
+                              obs_scale=args.obs_scale)
     assert env.num_envs == n and env.cfg.env_id_base == rank * n
     # synthetic input: uniform random actions in [0,5), one tape shared by the GPU and CPU runs
     T = TAPE_STEPS
@@ -292,7 +296,7 @@ def main():
     # steps exist up front, so it is reported beside the headline, not as it.  Every step's
     # observations go to their own slice of a T-step buffer (T x 16.3 MB), so all of them reach HBM.
     rollout = None
-    if rank == 0 and not args.python_loop and not args.no_rollout:
+    if rank == 0 and "tape" in legs:
         Tr = min(T, max(1, K))
         S = H * Wd * C
         obs_t = torch.empty((Tr, n, H, Wd, C), dtype=torch.uint8, device=dev)
@@ -324,7 +328,7 @@ def main():
 
     # secondary figure: per-step launches whose observations go to a per-step slice, as Runner.run keeps them
     strided = None
-    if rank == 0 and not args.python_loop and not args.no_rollout:
+    if rank == 0 and "strided" in legs:
         S = H * Wd * C
         Ts = max(2, min(64, (8 << 30) // (n * S)))  # 64 steps of 16.3 MB at the bench batch; at most 8 GB
         obs_s = torch.empty((Ts, n, H, Wd, C), dtype=torch.uint8, device=dev)
@@ -378,7 +382,7 @@ def main():
             "ms_per_step": round(med_ms / K, 6), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{n} envs/GPU x {DIM}x{DIM} x {N_SNAKES} snakes, snake_env rules, auto-reset, "
-                                   f"native {H}x{Wd}x{C} uint8 obs, uniform random actions (BASELINE configs[2]"
+                                   f"{'native' if args.obs_scale == 1 else 'fused x%d' % args.obs_scale} {H}x{Wd}x{C} uint8 obs, uniform random actions (BASELINE configs[2]"
                                    + ("/[3]" if world > 1 else "") + ")",
                        "envs_total": n * world, "agent_steps_per_s": round(value * N_SNAKES, 1),
                        "launch": "python per-step" if args.python_loop else "msnake_step_tape (C loop, 1 launch/step)",
@@ -409,7 +413,7 @@ def main():
                 "us_per_step": round(us, 3), "env_steps_per_s": round(n / us * 1e6, 1),
                 "algorithmic_frac_of_hbm_peak": round(bytes_per_launch / us / 1e3 / HBM_PEAK_GBS, 4)}
         out["collective"] = {"backend": total.get("backend"), "record_device": total.get("record_device"), "ranks": len(per_rank)}
-        if world == 1 and not args.no_rollout and not args.python_loop:
+        if world == 1 and "selfplay" in legs:
             out["selfplay_rollout"] = selfplay_rollout_leg(dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(tape_h)

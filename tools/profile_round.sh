@@ -4,16 +4,17 @@
 # bench.py command.  Output under gpurun_out/prof_<tag>/ ; tools/summarize_profile.py turns it into
 # the small files committed under profiles/.
 set -u
-# usage: tools/profile_round.sh <tag> [envs-per-gpu] [steps]     (defaults: the bench workload, 4 096 envs, 1 024 steps)
+# usage: tools/profile_round.sh <tag> [envs-per-gpu] [steps] [obs-scale]   (defaults: the bench workload, 4 096 envs, 1 024 steps, native)
 TAG=${1:-r01}
 ENVS=${2:-4096}
 STEPS=${3:-1024}
+SCALE=${4:-1}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps $STEPS --warmup 64 --repeats 1 --envs-per-gpu $ENVS --no-cpu-baseline --no-rollout"
+ARGS="--steps $STEPS --warmup 64 --repeats 1 --envs-per-gpu $ENVS --obs-scale $SCALE --no-cpu-baseline --no-rollout"
 # the same command without the profiler, on the same box: rocprofv3 serialises the dispatches and
 # lengthens both the kernels and the gaps between them, and boxes differ by a few per cent
 python3 $R/bench.py $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err || echo "plain bench failed"
