@@ -165,6 +165,21 @@ def load_pmc_traffic(bytes_per_launch):
                                             f"command recorded {d.get('recorded')}; not measured by this run)")
 
 
+def load_gap():
+    """(inter-kernel gap in us, source) of back-to-back msnake_step launches, from the newest committed span / gap record
+    (profiles/r*_span_gap_4096.json: wave stamps on the GPU's 100 MHz clock) -- a recorded figure, not a live one."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_span_gap_4096.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as fh:
+            d = json.load(fh)
+        return float(d["reading"]["gap_us"]), f"profiles/{os.path.basename(files[-1])} (tools/span_gap.py; not measured by this run)"
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
 def self_launch(args):
     """--gpus N > 1 without a torchrun environment: become the launcher.  Nothing in this process has
     touched the GPU (torch is not even imported yet), the ranks are ordinary child processes."""
@@ -235,7 +250,9 @@ def main():
                               obs_scale=args.obs_scale)
     assert env.num_envs == n and env.cfg.env_id_base == rank * n
     # synthetic input: uniform random actions in [0,5), one tape shared by the GPU and CPU runs
-    T = TAPE_STEPS
+    # (large batches wrap a shorter tape: 256 steps x 32 768 envs x 12 B = 100 MB of actions cycling through the 256 MB
+    #  Infinity Cache would evict the 130 MB observation buffer the plain-store regime keeps there; SURVEY 8(d)'s sweep uses 64)
+    T = TAPE_STEPS if n <= 8192 else 64
     tape_h = np.random.default_rng(1234 + rank).integers(0, 5, (T, n, N_SNAKES)).astype(np.int32)
     tape = torch.from_numpy(tape_h).to(dev)
     env.reset_device()
@@ -398,6 +415,15 @@ def main():
                          "kernel": env.kernel_name(), "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
+        gap_us, gap_src = load_gap()
+        if gap_us is not None and n == ENVS_PER_GPU and launch_us > gap_us:
+            # `launch_us` is the cadence of back-to-back launches = kernel span + the launch boundary (a fixed ~2 us between
+            # the last acknowledged store of one kernel and the first wave of the next); `achieved` / `frac` above are by the
+            # cadence.  The kernel's own span, and the fraction of peak it moves its bytes at, for the record:
+            out["roofline"]["launch_boundary_gap_us"] = gap_us
+            out["roofline"]["launch_boundary_gap_source"] = gap_src
+            out["roofline"]["kernel_span_us_est"] = round(launch_us - gap_us, 3)
+            out["roofline"]["frac_of_kernel_span_est"] = round(bytes_per_launch / (launch_us - gap_us) / 1e3 / HBM_PEAK_GBS, 4)
         if rollout is not None:
             out["rollout_tape"] = {
                 "what": f"same steps via msnake_rollout_tape: one persistent launch per {Tr}-step tape chunk, "
