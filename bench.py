@@ -217,6 +217,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # (selfplay_rollout leg: no exhaustive convolution search on first use)
     import torch
     import msnake
 

@@ -411,7 +411,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     constexpr bool PCACHE = RULES != MSNAKE_RULES_NEW_WORLD;  // new_world's fruits may fill the record
     uint32_t draws = 0, draw_base = 0, draws_n = 0;
     bool refilled = false;
+#ifdef MSNAKE_LATE_REFILL
     uint32_t slow_step = 0;  // != 0: this wave respawned a fruit or ended an episode in this launch (MODE 0 / 1)
+#endif
     // words 32..63 of a snake_env record only hold the Philox cache: they go back to memory in the launches
     // that change it (a Philox evaluation, the 2^32-draw wrap), not in every one.  (new_world keeps its fruits
     // there; the adversarial kernels have no SGPR to spare for the flag.)
@@ -1129,7 +1131,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         if (dbg & 0x1000) done = 0;
 #endif
         asm volatile("" : "+s"(done));  // (keeps it one SGPR: as a predicate it becomes a lane mask, a select and a compare)
+#ifdef MSNAKE_LATE_REFILL
         slow_step = done | (any_eat ? 1u : 0u);
+#endif
         if (done) {
             out_ret = ep_ret; out_len = ep_len;
             // logging totals stay in the env record (summed by msnake_get_stats): same-address

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--keep", type=float, default=0.6, help="probability of action 0 (snakes live longer)")
     ap.add_argument("--obs-every", type=int, default=25)
     ap.add_argument("--max-steps", type=int, default=2000)
+    ap.add_argument("--store-policy", default="auto", choices=["auto", "plain", "stream"], help="plain = the aligned copy-out")
     args = ap.parse_args()
     import torch
     import msnake
@@ -28,7 +29,7 @@ def main():
 
     n, ns = args.envs, args.snakes
     env = msnake.MultiSnakeVecEnv(n, dim=args.dim, n_snakes=ns, n_fruits=args.fruits, rules=args.rules, seed=77,
-                                  max_steps=args.max_steps)
+                                  max_steps=args.max_steps, obs_store_policy=args.store_policy)
     ora = Oracle(n, dim=args.dim, n_snakes=ns, n_fruits=args.fruits, rules=args.rules, seed=77, max_steps=args.max_steps)
     assert np.array_equal(env.reset(), ora.reset())
     rs = np.random.default_rng(5)
@@ -57,7 +58,7 @@ def main():
         maxlen = max(maxlen, max(len(b) for b in st["snakes"]))
     st = env.stats()
     assert st["errors"] == 0 and st["episodes"] == episodes
-    print(f"SOAK OK: {args.rules} {n} envs x {args.steps} steps, {episodes} episodes, "
+    print(f"SOAK OK: {args.rules} {n} envs x {args.steps} steps (store policy {args.store_policy}), {episodes} episodes, "
           f"longest body at the end {maxlen}, {time.time() - t0:.0f}s")
 
 
