@@ -246,7 +246,7 @@ int msnake_create(const msnake_config* cfg_in, msnake_handle* out) {
     // nt, so it never streams; neither does the persistent tape kernel (187 -> 208 us).
     {
         const double obs_mib = (double)p.nenv * p.S * p.obs_scale * p.obs_scale / (1024.0 * 1024.0);
-        p.rest.stream_obs = (p.obs_scale == 1 && (obs_mib <= 32.0 || obs_mib >= 192.0)) ? 1u : 0u;
+        p.rest.stream_obs = (p.obs_scale == 1 ? (obs_mib <= 32.0 || obs_mib >= 192.0) : obs_mib >= 400.0) ? 1u : 0u;
     }
     if (cfg->obs_store_policy != MSNAKE_AUTO) p.rest.stream_obs = cfg->obs_store_policy == MSNAKE_STORE_STREAM ? 1u : 0u;
 #ifdef MSNAKE_DBG_STAGES  // diagnostic builds only (tools/stamp_profile.py): never in the shipped library

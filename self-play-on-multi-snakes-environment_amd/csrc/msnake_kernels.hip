@@ -34,6 +34,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "msnake_internal.h"
 
 namespace msnake {
@@ -176,6 +178,7 @@ __device__ __forceinline__ uint32_t hv_writelane_unrolled(uint32_t old, uint32_t
 typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
+typedef u32x4 __attribute__((aligned(4))) u32x4_dw;  // 16 bytes at a dword-aligned address
 
 // One snake pixel in the C = 3*VIEWS interleaved channels: view v shows snake J as "self" when v == J.
 // body: self (0,204,0) / other (0,51,204); head: self (191,242,191) / other (128,154,230)
@@ -269,12 +272,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     constexpr int FR0 = RULES == MSNAKE_RULES_NEW_WORLD ? HDR_FRUIT0_N : HDR_FRUIT0_S;
     // the persistent tape kernel keeps a pristine copy of the background in LDS (native size only)
     constexpr bool LDSBG = MODE == 3 && K == 1;
-    // Aligned copy-out (native size, per-step launches, plain stores -- the batches whose observations fit the Infinity
-    // Cache): the image is composed `shift` = (address of the env's observation) & 15 bytes into its LDS buffer, over
-    // background number `shift` of the 16 pre-shifted ones, so that both sides of every 16-byte chunk of the copy-out
-    // are 16-byte aligned and every wave instruction stores whole 128-byte lines.  Streaming (nt) launches keep the
-    // image at offset 0 and byte-aligned stores: their partly written sectors are what makes nt stores leave the L2
-    // early (whole-line stores stay, nt or not, and the state loads of later waves queue behind their eviction).
+    // Aligned copy-out (native size, per-step launches): the image is composed `shift` = (address of the env's observation)
+    // & 15 bytes into its LDS buffer, over background number `shift` of the 16 pre-shifted ones, so that both sides of every
+    // 16-byte chunk of the copy-out are 16-byte aligned and every wave instruction stores whole 128-byte lines (step 7a).
+    // The persistent tape kernel keeps the image at offset 0 and byte-aligned stores (its background lives in LDS).
     constexpr int TMPL_COPIES = K == 1 ? MSNAKE_TMPL_COPIES : 1;
     constexpr bool CAN_ALIGN = K == 1 && MODE != 3;
     auto unpack = [&]() {
@@ -670,12 +671,12 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 abatch = (uint32_t)actions[((size_t)t * (size_t)nenv + (size_t)e) * action_stride + (lane & 3)];
         }
     }
-    // aligned copy-out: where in its LDS buffer the image starts (0 for streaming launches, see CAN_ALIGN)
+    // aligned copy-out: where in its LDS buffer the image starts (see CAN_ALIGN)
     // (derived where it is used -- three scalar instructions -- instead of being held in an SGPR for the whole kernel)
     auto obs_shift_of = [&]() -> uint32_t {
         uint32_t ee = (uint32_t)e;
         if (FENCED) asm volatile("" : "+s"(ee));
-        return (CAN_ALIGN && obs_t && !(pk2 & PK2_STREAM_OBS)) ? (((uint32_t)(uintptr_t)obs_t + ee * (uint32_t)S) & 15u) : 0u;
+        return (CAN_ALIGN && obs_t) ? (((uint32_t)(uintptr_t)obs_t + ee * (uint32_t)S) & 15u) : 0u;
     };
     // background image (black interior, white wall ring): one L1/L2-resident copy shared by every
     // wave, a whole number of 1 KiB wave-instructions so that no lane needs a predicate.
@@ -1236,26 +1237,41 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #ifdef MSNAKE_DBG_STAGES
         if (dbg == 6) asm volatile("s_endpgm");
 #endif
-        if (CAN_ALIGN && !(pk2 & PK2_STREAM_OBS)) {
-            // ---- 7a. aligned copy-out (plain stores): LDS byte x of the buffer <-> global byte g_al + x, both sides 16-byte
-            //          aligned; wave instruction i covers the i-th KiB counted from the 128-byte line the image starts
-            //          in, so every store instruction writes whole lines (1.00 x the image in WRITE_SIZE; the byte-aligned
-            //          stores below write the sectors at their instruction boundaries twice: 1.07 x).  The <= 15 bytes in
-            //          front of the first whole chunk and behind the last one go singly.
-            //          Measured (round 3, same box): 23.2-23.7 vs 24.9-26.2 us at 32 768 envs, 13.96 vs 15.21 at 16 384.
+        if (CAN_ALIGN) {
+            // ---- 7a. aligned copy-out (per-step launches): LDS byte x of the buffer <-> global byte g_al + x, both sides
+            //          16-byte aligned; wave instruction i covers the i-th KiB counted from the 128-byte line the image
+            //          starts in, so every store instruction writes whole lines (WRITE_SIZE 1.00-1.02 x the image; the
+            //          byte-aligned stores of 7 below write the sectors at their instruction boundaries twice: 1.07 x).
+            //          The <= 15 bytes in front of the first whole chunk and behind the last one go singly.  Streaming (nt)
+            //          or plain stores by obs_store_policy.  Measured (round 3, same box each): nt, 262 144 envs 195-200 vs
+            //          214-219 us, 131 072 envs 94.5 vs 110, 65 536 envs 48.6 vs 55.5; plain, 32 768 envs 23.2-23.7 vs
+            //          24.9-26.2, 16 384 envs 13.96 vs 15.21; nt, 4 096 envs: no difference.
             uint8_t* obs_env = obs_t + (size_t)e * S;
             const uint32_t obs_shift = obs_shift_of();
             uint8_t* g_al = obs_env - obs_shift;
             const int lead = (int)(((uint32_t)(uintptr_t)g_al >> 4) & 7u);  // chunks between the start of the 128-byte line and g_al
             const int end = (int)obs_shift + DBG_NO_OBS_STORES(S);           // the image = buffer bytes [shift, end)
+            // (two copies of the loop, one per store kind: written as `if (nt) nt-store else store` on one value and one
+            //  address, the compiler merges the two stores into a plain one -- the nontemporal hint is droppable metadata --
+            //  and a "streaming" launch then thrashes the L2s like a plain one: 374 instead of 196 us at 262 144 envs)
+            auto chunks = [&](auto NT) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = 64 * i + lane - lead;
-                if (k >= 0 && 16 * k >= (int)obs_shift && 16 * k + 16 <= end DBG_FEWER_STORES(i))
-                    *reinterpret_cast<uint4*>(g_al + 16 * k) = *reinterpret_cast<const uint4*>(img + 16 * k);
-            }
-            for (int k = 256 + lane - lead; 16 * k + 16 <= end; k += 64)     // (images beyond 4 KiB)
-                *reinterpret_cast<uint4*>(g_al + 16 * k) = *reinterpret_cast<const uint4*>(img + 16 * k);
+                for (int i = 0; i < 4; ++i) {
+                    const int k = 64 * i + lane - lead;
+                    if (k >= 0 && 16 * k >= (int)obs_shift && 16 * k + 16 <= end DBG_FEWER_STORES(i)) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(img + 16 * k);
+                        if constexpr (decltype(NT)::value) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(g_al + 16 * k));
+                        else *reinterpret_cast<u32x4*>(g_al + 16 * k) = v;
+                    }
+                }
+                for (int k = 256 + lane - lead; 16 * k + 16 <= end; k += 64) {   // (images beyond 4 KiB)
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(img + 16 * k);
+                    if constexpr (decltype(NT)::value) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(g_al + 16 * k));
+                    else *reinterpret_cast<u32x4*>(g_al + 16 * k) = v;
+                }
+            };
+            if (pk2 & PK2_STREAM_OBS) chunks(std::true_type{});
+            else chunks(std::false_type{});
             // head bytes [shift, 16) on lanes 0..15 (when shift > 0), tail bytes [end & ~15, end) on lanes 16..31
             const int byte = lane < 16 ? lane : (end & ~15) + (lane - 16);
             const bool on = lane < 16 ? (obs_shift != 0 && lane >= (int)obs_shift && lane < end) : (lane < 32 && byte < end && byte >= 16);
@@ -1308,12 +1324,34 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             uint32_t* out = reinterpret_cast<uint32_t*>(obs_t + (size_t)e * S * (K * K));
             const uint32_t* src = reinterpret_cast<const uint32_t*>(img);
             const int rowdw = (W * K * C) >> 2;
-            // (Round 3, measured and rejected: the contiguous 63 504-byte frame written as 16-byte-per-lane stores, every
-            //  wave instruction covering whole 128-byte lines -- rows are dword-, not 16-byte multiples, so chunks are
-            //  re-cut across rows -- with plain or nt stores: 40.0 / 40.8 vs 38.2 us at 4 096 envs, 399.6 / 416.3 vs
-            //  404.7 us at 32 768.  A logic-free kernel storing 62 KiB per wave reaches 5.4-5.65 TB/s on this chip
-            //  (tools/probes/write_bw_probe.hip); these 2 GB launches run at 5.2: the store stream is at its roofline.)
-            {
+            if (MODE != 3 && (pk2 & PK2_STREAM_OBS)) {
+                // ---- 7b. streaming launches of the fused frames (>= 400 MiB per launch, far beyond the Infinity Cache; the
+                //          launch glue sets the bit only when every frame is 16-byte aligned): the frame is ONE contiguous run
+                //          of W*K rows of rowB bytes and leaves as 16-byte-per-lane nt stores, every wave instruction writing
+                //          1 KiB of whole 128-byte lines (the first one starts at the line the frame starts in: its leading
+                //          lanes sit out).  A chunk inside one output row is 16 contiguous bytes of the LDS row it replicates
+                //          (dword-aligned: rows are whole dwords, not 16-byte multiples); a chunk that straddles two rows holds
+                //          the last <= 12 bytes of one and the first <= 12 of the next, wall pixels (255) in every row.
+                //          Measured, same box: 398 vs 418 us at 32 768 envs (2 GB), 105.8 vs 108.6 at 8 192; at 4 096 envs
+                //          (248 MiB, still cache resident) the dword stores below win, 37.7 vs 42.7 (plain) / 55.7 (nt).
+                const uint32_t rowB = (uint32_t)(W * K * C), OB = rowB * (uint32_t)(W * K);
+                uint8_t* g0 = obs_t + (size_t)e * OB;
+                const int32_t head = (int32_t)((uint32_t)(uintptr_t)g0 & 127u);
+                const float inv = 1.0f / (float)rowB;
+                for (int32_t o = 16 * lane - head; o < (int32_t)OB; o += 1024) {
+                    if (o < 0) continue;  // (first instruction only)
+                    // output row and column of the chunk: o / rowB by a float reciprocal (o < 2^24: exact in float) + one fix-up
+                    int32_t orow = (int32_t)((float)o * inv);
+                    int32_t c = o - orow * (int32_t)rowB;
+                    if (c < 0) { orow -= 1; c += (int32_t)rowB; }
+                    if (c >= (int32_t)rowB) { orow += 1; c -= (int32_t)rowB; }
+                    const bool straddle = c > (int32_t)rowB - 16;
+                    const int32_t cc = straddle ? (int32_t)rowB - 16 : c;
+                    u32x4 v = *reinterpret_cast<const u32x4_dw*>(img + (uint32_t)(orow / K) * rowB + (uint32_t)cc);
+                    if (straddle) v = u32x4{~0u, ~0u, ~0u, ~0u};
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(g0 + o));
+                }
+            } else {
                 for (int r = 0; r < W; ++r)
                     for (int q = lane; q < rowdw; q += 64) {
                         const uint32_t v = src[r * rowdw + q];
@@ -1637,8 +1675,14 @@ static hipError_t launch_k(const StepParams& p, int mode, int epb, hipStream_t s
         if (lds_wave > 64 * 1024) return hipErrorInvalidValue;
     }
     const size_t lds = lds_wave * (size_t)epb;
-    // (the dword stores of the fused x4 / x7 copy-out never stream: 256 B per wave instruction, 2.5x slower with nt)
-    const uint32_t pk2 = (p.short_rec ? PK2_SHORT_REC : 0u) | (p.rest.stream_obs && K == 1 ? PK2_STREAM_OBS : 0u) |
+    // fused x4 / x7 frames stream only in the flat 16-byte shape, which needs every frame 16-byte aligned (the dword stores
+    // never stream: 256 B per wave instruction, 2.5x slower with nt); the persistent kernel's fused copy-out never does
+    bool nt_obs = p.rest.stream_obs != 0;
+    if (K > 1) {
+        const size_t OB = (size_t)p.S * K * K;
+        nt_obs = nt_obs && mode != 3 && p.obs && OB % 16 == 0 && ((uintptr_t)p.obs & 15) == 0 && OB < (1u << 24);
+    }
+    const uint32_t pk2 = (p.short_rec ? PK2_SHORT_REC : 0u) | (nt_obs ? PK2_STREAM_OBS : 0u) |
                          (p.stream_tape && K == 1 ? PK2_STREAM_TAPE : 0u) | ((uint32_t)epb << PK2_EPB_SHIFT) |
                          (div_magic((uint32_t)p.dim) << PK2_DIVM_SHIFT);
     const dim3 grid((unsigned)((((p.nenv + epb - 1) / epb) + 63) & ~63));  // whole groups of 64: see the kernel's XCD swap

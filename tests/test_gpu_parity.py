@@ -948,3 +948,36 @@ def test_fused_warpframe_copy_out_variants(lead):
     host = buf.cpu().numpy()
     assert (host[:lead] == 0xAB).all() and (host[lead + nbytes:] == 0xAB).all()
     env.close()
+
+
+@pytest.mark.parametrize("dim,n_snakes,rules,scale,lead", [(19, 3, "snake_env", 4, 0), (19, 3, "snake_env", 4, 48), (19, 3, "snake_env", 4, 4),
+                                                           (10, 1, "snake_env", 7, 16), (10, 2, "new_world", 7, 0), (19, 1, "new_world", 4, 32),
+                                                           (10, 2, "adversarial", 7, 112), (19, 4, "new_world", 4, 0)])
+def test_fused_warpframe_streaming_flat_copy_out(dim, n_snakes, rules, scale, lead):
+    """Fused frames beyond ~400 MiB per launch stream: the contiguous frame leaves as 16-byte-per-lane nt stores over whole
+    128-byte lines, chunks re-cut across the (dword-, not 16-byte-multiple) rows, row-straddling chunks = wall pixels.
+    Forced here at a small batch through obs_store_policy="stream", at several positions of the frame inside its first
+    line (lead 0 / 16 / 32 / 48 / 112) and with a buffer that is only 4-byte aligned (lead 4: dword fallback)."""
+    import torch
+    from oracle.snake_oracle import Oracle
+    n = 130
+    env = _mk(num_envs=n, dim=dim, n_snakes=n_snakes, rules=rules, seed=45, obs_scale=scale, obs_store_policy="stream")
+    ora = Oracle(n, dim=dim, n_snakes=n_snakes, rules=rules, seed=45)
+    H, W, C = env.obs_shape
+    nbytes = n * H * W * C
+    buf = torch.full((nbytes + 256,), 0xAB, dtype=torch.uint8, device=env.device)
+    assert buf.data_ptr() % 256 == 0
+    out = buf[lead:lead + nbytes].view(n, H, W, C)
+    up = lambda o: np.repeat(np.repeat(o, scale, axis=1), scale, axis=2)
+    assert np.array_equal(env.reset_device(out=out).cpu().numpy(), up(ora.reset()))
+    rs = np.random.default_rng(lead)
+    for t in range(30):
+        act = rs.integers(0, 5, (n, n_snakes)).astype(np.int32)
+        obs, rew, done, _ = env.step_device(torch.from_numpy(act).to(env.device), out=out)
+        o_obs, o_rew, o_done, _, _, _ = ora.step(act)
+        assert np.array_equal(obs.cpu().numpy(), up(o_obs)), t
+        assert np.array_equal(rew.cpu().numpy(), o_rew) and np.array_equal(done.cpu().numpy(), o_done), t
+    assert np.array_equal(env.render_device(out=out).cpu().numpy(), up(ora.render()))
+    host = buf.cpu().numpy()
+    assert (host[:lead] == 0xAB).all() and (host[lead + nbytes:] == 0xAB).all()
+    env.close()
