@@ -1404,6 +1404,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         if ((lane < MSNAKE_HDR_SHORT_WORDS || (!short_rec && upper_dirty))) {
             uint32_t ee = (uint32_t)e;
             if (MODE == 3) asm volatile("" : "+s"(ee));  // (the pointer is not held across the step loop)
+            // (round 3: the nt hint on this store, on the ring-sector stores and on the reward store -- nothing left dirty in the
+            //  L2s for the end-of-kernel release -- changes nothing: 5.77-5.79 / 5.76-5.79 vs 5.75-5.78 us, and costs with the
+            //  4-byte reward stores in: 5.92-5.95)
             (reinterpret_cast<uint32_t*>(state) + (size_t)ee * MSNAKE_HDR_WORDS)[lane] = hv;
         }
         if (RULES == MSNAKE_RULES_ADVERSARIAL && fr_dirty) fl0_of()[lane] = (uint16_t)fr;
