@@ -20,8 +20,9 @@
 //     cell; Philox4x32-10 on the VALU, lane l computing draw ctr + l (one evaluation = 64 draws);
 //   * the observation is composed in LDS: the wall/background image (L1/L2-resident) goes memory ->
 //     LDS directly (global_load_lds_dwordx4, no data VGPRs), fruit and body pixels are painted over
-//     it in reference order, and the image leaves as 16-byte-per-lane global stores (1 KiB contiguous
-//     per wave instruction);
+//     it in reference order, and the image leaves as 16-byte-per-lane global stores, 1 KiB of whole
+//     128-byte lines per wave instruction: the image is composed at ITS OWN alignment in LDS (16
+//     pre-shifted backgrounds), so both sides of every chunk are 16-byte aligned;
 //   * write-back = what changed: the record, one 32-byte sector per moving snake, the outputs.
 // Integer / byte work bounded by the HBM writes of the observation tensor; no MFMA on purpose.
 //
@@ -1277,10 +1278,11 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             const bool on = lane < 16 ? (obs_shift != 0 && lane >= (int)obs_shift && lane < end) : (lane < 32 && byte < end && byte >= 16);
             if (on) g_al[byte] = img[byte];
         } else if (K == 1) {
-            // ---- 7. LDS image -> HBM: 16 bytes per lane, 1 KiB contiguous per wave instruction.
-            //         The 3969-byte images are not 16-byte multiples, so the global side is
-            //         byte-aligned (the hardware splits the few lines that straddle); the last
-            //         S%16 bytes go singly.
+            // ---- 7. the persistent tape kernel's copy-out (and, until round 3, every launch's): LDS image -> HBM, 16 bytes
+            //         per lane, 1 KiB contiguous per wave instruction.  The 3969-byte images are not 16-byte multiples,
+            //         so the global side is byte-aligned (the hardware splits the lines that straddle; the sectors at the
+            //         instruction boundaries go out twice: WRITE_SIZE 1.07 x the image); the last S%16 bytes go singly.
+            //         The notes below were measured on per-step launches in rounds 1-2, which now take step 7a.
             uint8_t* obs_env = obs_t + (size_t)e * S;
             const int nfull = DBG_NO_OBS_STORES(S) >> 4;
             // One LDS read -> one store per KiB, in a plain loop.  (Measured and rejected, same box:
@@ -1291,7 +1293,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             // (Streaming stores for the interior and plain ones for the first / last 128 bytes of each
             //  image, so that the edge cache lines two neighbouring images share meet in L2: WRITE_SIZE
             //  drops from 4 424 to 4 189 B per env at 262 144 envs, and the launch takes 387 instead of
-            //  206-232 us -- mixing the two store kinds on one region is ruinous.  Rejected.)
+            //  206-232 us -- "mixing the two store kinds on one region is ruinous", round 2 concluded.  387 us is what plain
+            //  stores take there: most likely the compiler had merged the nt store of that experiment into the plain one, as
+            //  it did in round 3's first aligned copy-out, see step 7a.)
             // (Round 2, same box each: the LDS read of KiB i+1 in flight while KiB i is stored -- 6.52-6.58 vs
             //  6.52-6.58 us, no change; other cache policies for the 16-byte stores than `nt`: sc1 6.2-6.5,
             //  sc0 sc1 6.1-6.4, sc0 7.0, nt sc1 8.3, plain 7.6 against 5.91 us for `nt`.  A quarter of the stores
