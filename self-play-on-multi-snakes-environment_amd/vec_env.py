@@ -141,6 +141,11 @@ class MultiSnakeVecEnv:
         self._pending = None
         self._tstart = time.time()
         self.closed = False
+        # hot-path constants of step_device(): the handle's own output buffers never move
+        self._p_obs, self._p_rew = self._obs.data_ptr(), self._rew.data_ptr()
+        self._p_done, self._p_info = self._done.data_ptr(), self._info.data_ptr()
+        self._step_fn = self._L.msnake_step
+        self._cur_stream = torch.cuda.current_stream
 
     # ------------------------------------------------------------------ device-side API
     def _stream(self):
@@ -170,12 +175,18 @@ class MultiSnakeVecEnv:
         torch = self._torch
         if actions.dtype != torch.int32 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
-        if actions.dim() != 2 or actions.shape[0] != self.num_envs or actions.shape[1] < self.n_snakes:
+        shape = actions.shape
+        if len(shape) != 2 or shape[0] != self.num_envs or shape[1] < self.n_snakes:
             raise ValueError(f"actions must be [{self.num_envs}, >={self.n_snakes}], got {tuple(actions.shape)}")
-        obs = self._out(out)
-        _capi.check(self._L.msnake_step(self._h, actions.data_ptr(), int(actions.shape[1]), obs.data_ptr(),
-                                        self._rew.data_ptr(), self._done.data_ptr(), self._info.data_ptr(),
-                                        self._stream()), "msnake_step")
+        if out is None:
+            obs, p_obs = self._obs, self._p_obs
+        else:
+            obs = self._out(out)
+            p_obs = obs.data_ptr()
+        rc = self._step_fn(self._h, actions.data_ptr(), shape[1], p_obs, self._p_rew, self._p_done, self._p_info,
+                           self._cur_stream(self.device).cuda_stream)
+        if rc < 0:
+            _capi.check(rc, "msnake_step")
         return obs, self._rew, self._done, self._info
 
     def rollout_device(self, tape, persistent=True, keep_obs=True):
