@@ -692,8 +692,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #else
     if (obs_t && (!LDSBG || step_i == 0)) {
 #endif
-        const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl_of()) + lane;
-        if (CAN_ALIGN) tsrc += obs_shift_of() * (uint32_t)(img_bytes >> 4);  // background number `shift`: the image starts `shift` bytes into it
+        // (aligned copy-out: background number `shift`, the image starts `shift` bytes into it; the offset joins the scalar base)
+        const uint4* tsrc = reinterpret_cast<const uint4*>(tmpl_of() + (CAN_ALIGN ? obs_shift_of() * (uint32_t)img_bytes : 0u)) + lane;
         uint8_t* dst = LDSBG ? bg : img;
         const int nk = img_bytes >> 10;
 #define MSNAKE_GP(k) ((const __attribute__((address_space(1))) void*)(tsrc + (k) * 64))
@@ -1252,24 +1252,32 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             uint8_t* g_al = obs_env - obs_shift;
             const int lead = (int)(((uint32_t)(uintptr_t)g_al >> 4) & 7u);  // chunks between the start of the 128-byte line and g_al
             const int end = (int)obs_shift + DBG_NO_OBS_STORES(S);           // the image = buffer bytes [shift, end)
+            // whole chunks: k in [kmin, kmin + nk); lane l of instruction i holds chunk 64 i + l - lead: ONE address pair per
+            // side, the instruction offset steps through the KiB, ONE unsigned compare per instruction
+            const int kmin = (int)((obs_shift + 15u) >> 4);
+            const uint32_t nk = (uint32_t)((end >> 4) - kmin);
+            const int k0 = lane - lead;
+            const uint32_t rel = (uint32_t)(k0 - kmin);
+            const uint8_t* lsrc = img + 16 * k0;
+            uint8_t* gdst = g_al + 16 * k0;
             // (two copies of the loop, one per store kind: written as `if (nt) nt-store else store` on one value and one
             //  address, the compiler merges the two stores into a plain one -- the nontemporal hint is droppable metadata --
             //  and a "streaming" launch then thrashes the L2s like a plain one: 374 instead of 196 us at 262 144 envs)
             auto chunks = [&](auto NT) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int k = 64 * i + lane - lead;
-                    if (k >= 0 && 16 * k >= (int)obs_shift && 16 * k + 16 <= end DBG_FEWER_STORES(i)) {
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(img + 16 * k);
-                        if constexpr (decltype(NT)::value) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(g_al + 16 * k));
-                        else *reinterpret_cast<u32x4*>(g_al + 16 * k) = v;
+                    if (rel + 64u * i < nk DBG_FEWER_STORES(i)) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(lsrc + 1024 * i);
+                        if constexpr (decltype(NT)::value) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(gdst + 1024 * i));
+                        else *reinterpret_cast<u32x4*>(gdst + 1024 * i) = v;
                     }
                 }
-                for (int k = 256 + lane - lead; 16 * k + 16 <= end; k += 64) {   // (images beyond 4 KiB)
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(img + 16 * k);
-                    if constexpr (decltype(NT)::value) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(g_al + 16 * k));
-                    else *reinterpret_cast<u32x4*>(g_al + 16 * k) = v;
-                }
+                if (nk + (uint32_t)(kmin + lead) > 256u)                     // (images beyond 4 KiB)
+                    for (uint32_t r = rel + 256u; r < nk; r += 64u) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(lsrc + 16 * (r - rel));
+                        if constexpr (decltype(NT)::value) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(gdst + 16 * (size_t)(r - rel)));
+                        else *reinterpret_cast<u32x4*>(gdst + 16 * (size_t)(r - rel)) = v;
+                    }
             };
             if (pk2 & PK2_STREAM_OBS) chunks(std::true_type{});
             else chunks(std::false_type{});
