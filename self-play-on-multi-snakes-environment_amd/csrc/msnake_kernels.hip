@@ -278,7 +278,11 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // 16-byte chunk of the copy-out are 16-byte aligned and every wave instruction stores whole 128-byte lines (step 7a).
     // The persistent tape kernel keeps the image at offset 0 and byte-aligned stores (its background lives in LDS).
     constexpr int TMPL_COPIES = K == 1 ? MSNAKE_TMPL_COPIES : 1;
+#ifdef MSNAKE_NO_ALIGN  // (A/B builds: every launch takes the byte-aligned copy-out of rounds 1-2)
+    constexpr bool CAN_ALIGN = false;
+#else
     constexpr bool CAN_ALIGN = K == 1 && MODE != 3;
+#endif
     auto unpack = [&]() {
         dim = (int)(pk0v & 63u); nf = (int)((pk0v >> 6) & 63u); action_stride = (int)((pk0v >> 12) & 7u);
         auto_reset = (pk0v >> 15) & 1u;
