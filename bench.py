@@ -251,9 +251,13 @@ def main():
                               obs_scale=args.obs_scale)
     assert env.num_envs == n and env.cfg.env_id_base == rank * n
     # synthetic input: uniform random actions in [0,5), one tape shared by the GPU and CPU runs
-    # (large batches wrap a shorter tape: 256 steps x 32 768 envs x 12 B = 100 MB of actions cycling through the 256 MB
-    #  Infinity Cache would evict the 130 MB observation buffer the plain-store regime keeps there; SURVEY 8(d)'s sweep uses 64)
-    T = TAPE_STEPS if n <= 8192 else 64
+    # (large batches wrap a shorter tape, kept below 32 MiB: what cycles through the 256 MB Infinity Cache beside the launch
+    #  decides whether the env state (640 B per env) and, in the plain-store range, the observation buffer stay resident --
+    #  at 262 144 envs the same launch takes 191 us with an 8- or 32-step tape, 210 with 64 steps (201 MB), 222 with 128;
+    #  a caller with a policy in the loop has no tape at all: its actions are one 12-byte-per-env tensor per step)
+    T = TAPE_STEPS
+    while T > 8 and T * n * N_SNAKES * 4 > (32 << 20):
+        T //= 2
     tape_h = np.random.default_rng(1234 + rank).integers(0, 5, (T, n, N_SNAKES)).astype(np.int32)
     tape = torch.from_numpy(tape_h).to(dev)
     env.reset_device()

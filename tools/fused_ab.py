@@ -17,6 +17,8 @@ for n in sizes:
         env = msnake.MultiSnakeVecEnv(n, dim=19, n_snakes=3, seed=0, obs_scale=4, obs_store_policy=pol)
         env.reset_device()
         T = 32
+        while T > 8 and T * n * 3 * 4 > (32 << 20):
+            T //= 2
         tape = torch.from_numpy(np.random.default_rng(1234).integers(0, 5, (T, n, 3)).astype(np.int32)).cuda()
         L, h = env._L, env._h
         steps = 512 if n <= 8192 else 96

@@ -30,6 +30,8 @@ def main():
                                        obs_store_policy=args.store_policy, record_policy=args.record_policy, envs_per_block=args.epb)
         env.reset_device()
         T = 64
+        while T > 8 and T * n * args.snakes * 4 > (32 << 20):  # (the action tape stays below 32 MiB: see bench.py)
+            T //= 2
         tape = torch.randint(0, 5, (T, n, args.snakes), dtype=torch.int32, device=dev)
         L, h = env._L, env._h
         obs, rew, done, info = env._obs, env._rew, env._done, env._info

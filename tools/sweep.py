@@ -28,6 +28,8 @@ for name, n, dim, ns, scale, steps in CASES:
     env = msnake.MultiSnakeVecEnv(n, dim=dim, n_snakes=ns, seed=0, device=dev, obs_scale=scale)
     env.reset_device()
     T = 64
+    while T > 8 and T * n * ns * 4 > (32 << 20):  # (the action tape stays below 32 MiB: see bench.py)
+        T //= 2
     rng = np.random.default_rng(1234)
     tape = torch.from_numpy(rng.integers(0, 5, size=(T, n, ns), dtype=np.int32)).to(dev)
     L, h = env._L, env._h
