@@ -83,6 +83,7 @@ struct StepRest {
 #define PK2_SHORT_REC 1u   // move only the first 128 bytes of each record
 #define PK2_STREAM_OBS 2u  // observation stores carry the nt (streaming) hint (fused frames: the flat 16-byte copy-out)
 #define PK2_STREAM_TAPE 4u // same for the persistent tape kernel (msnake_rollout_tape)
+#define PK2_TAPE_ALIGNED 8u // msnake_rollout_tape: the step stride is a multiple of 16 bytes -> aligned copy-out for every step
 #define PK2_EPB_SHIFT 8    // bits 8..15: envs (waves) per workgroup
 #define PK2_DIVM_SHIFT 16  // bits 16..31: the multiplier of the division-free x / dim (slow paths)
 

@@ -281,8 +281,11 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #ifdef MSNAKE_NO_ALIGN  // (A/B builds: every launch takes the byte-aligned copy-out of rounds 1-2)
     constexpr bool CAN_ALIGN = false;
 #else
-    constexpr bool CAN_ALIGN = K == 1 && MODE != 3;
+    constexpr bool CAN_ALIGN = K == 1;
 #endif
+    // (the persistent tape kernel: only when every step's observations keep the alignment of the first step's, i.e. the
+    //  step stride is a multiple of 16 bytes -- the launch glue checks -- so that its LDS-resident background fits all steps)
+    const bool align_now = CAN_ALIGN && (MODE != 3 || (pk2 & PK2_TAPE_ALIGNED));
     auto unpack = [&]() {
         dim = (int)(pk0v & 63u); nf = (int)((pk0v >> 6) & 63u); action_stride = (int)((pk0v >> 12) & 7u);
         auto_reset = (pk0v >> 15) & 1u;
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     auto obs_shift_of = [&]() -> uint32_t {
         uint32_t ee = (uint32_t)e;
         if (FENCED) asm volatile("" : "+s"(ee));
-        return (CAN_ALIGN && obs_t) ? (((uint32_t)(uintptr_t)obs_t + ee * (uint32_t)S) & 15u) : 0u;
+        return (align_now && obs_t) ? (((uint32_t)(uintptr_t)obs_t + ee * (uint32_t)S) & 15u) : 0u;
     };
     // background image (black interior, white wall ring): one L1/L2-resident copy shared by every
     // wave, a whole number of 1 KiB wave-instructions so that no lane needs a predicate.
@@ -1242,8 +1245,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #ifdef MSNAKE_DBG_STAGES
         if (dbg == 6) asm volatile("s_endpgm");
 #endif
-        if (CAN_ALIGN) {
-            // ---- 7a. aligned copy-out (per-step launches): LDS byte x of the buffer <-> global byte g_al + x, both sides
+        if (align_now) {
+            // ---- 7a. aligned copy-out (per-step launches; tapes whose step stride is a multiple of 16 bytes): LDS byte x of the buffer <-> global byte g_al + x, both sides
             //          16-byte aligned; wave instruction i covers the i-th KiB counted from the 128-byte line the image
             //          starts in, so every store instruction writes whole lines (WRITE_SIZE 1.00-1.02 x the image; the
             //          byte-aligned stores of 7 below write the sectors at their instruction boundaries twice: 1.07 x).
@@ -1283,7 +1286,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                         else *reinterpret_cast<u32x4*>(gdst + 16 * (size_t)(r - rel)) = v;
                     }
             };
-            if (pk2 & PK2_STREAM_OBS) chunks(std::true_type{});
+            if (pk2 & (MODE == 3 ? PK2_STREAM_TAPE : PK2_STREAM_OBS)) chunks(std::true_type{});
             else chunks(std::false_type{});
             // head bytes [shift, 16) on lanes 0..15 (when shift > 0), tail bytes [end & ~15, end) on lanes 16..31
             const int byte = lane < 16 ? lane : (end & ~15) + (lane - 16);
@@ -1702,7 +1705,8 @@ static hipError_t launch_k(const StepParams& p, int mode, int epb, hipStream_t s
         nt_obs = nt_obs && mode != 3 && p.obs && OB % 16 == 0 && ((uintptr_t)p.obs & 15) == 0 && OB < (1u << 24);
     }
     const uint32_t pk2 = (p.short_rec ? PK2_SHORT_REC : 0u) | (nt_obs ? PK2_STREAM_OBS : 0u) |
-                         (p.stream_tape && K == 1 ? PK2_STREAM_TAPE : 0u) | ((uint32_t)epb << PK2_EPB_SHIFT) |
+                         (p.stream_tape && K == 1 ? PK2_STREAM_TAPE : 0u) |
+                         (mode == 3 && K == 1 && p.rest.obs_step_stride % 16 == 0 ? PK2_TAPE_ALIGNED : 0u) | ((uint32_t)epb << PK2_EPB_SHIFT) |
                          (div_magic((uint32_t)p.dim) << PK2_DIVM_SHIFT);
     const dim3 grid((unsigned)((((p.nenv + epb - 1) / epb) + 63) & ~63));  // whole groups of 64: see the kernel's XCD swap
     const dim3 block(64u * (unsigned)epb);

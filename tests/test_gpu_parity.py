@@ -981,3 +981,27 @@ def test_fused_warpframe_streaming_flat_copy_out(dim, n_snakes, rules, scale, le
     host = buf.cpu().numpy()
     assert (host[:lead] == 0xAB).all() and (host[lead + nbytes:] == 0xAB).all()
     env.close()
+
+
+@pytest.mark.parametrize("n,policy", [(512, "stream"), (512, "plain"), (520, "stream"), (777, "stream"), (4096, "auto")])
+def test_persistent_tape_copy_out_shapes(n, policy):
+    """msnake_rollout_tape copies out in the aligned whole-line shape when every step's observations keep one alignment
+    (step stride = n * 3969 bytes a multiple of 16: n = 512, 4 096) and in the byte-aligned shape otherwise (520, 777), with
+    plain or streaming stores (tape_store_policy; "auto" streams from 192 MiB per call: 4 096 envs x 16 steps = 260 MB).
+    Same bytes as per-step launches either way, and as a re-used (stride 0) buffer's last step."""
+    import torch
+    T = 16
+    kw = dict(num_envs=n, dim=19, n_snakes=3, rules="snake_env", seed=93)
+    a, b = _mk(tape_store_policy=policy, **kw), _mk(**kw)
+    a.reset(); b.reset()
+    tape = torch.randint(0, 5, (2 * T, n, 3), dtype=torch.int32, device=a.device)
+    o1, r1, d1, i1 = a.rollout_device(tape[:T])
+    for t in range(T):
+        o, r, d, i = b.step_device(tape[t])
+        assert torch.equal(o, o1[t]) and torch.equal(r, r1[t]) and torch.equal(d, d1[t]) and torch.equal(i, i1[t]), t
+    o2, r2, d2, i2 = a.rollout_device(tape[T:], keep_obs=False)
+    for t in range(T, 2 * T):
+        o, r, d, i = b.step_device(tape[t])
+    assert torch.equal(o, o2) and torch.equal(r, r2[-1]) and torch.equal(d, d2[-1])
+    assert a.stats() == b.stats()
+    a.close(); b.close()
