@@ -204,6 +204,7 @@ def main():
     ap.add_argument("--python-loop", action="store_true", help="issue launches from Python instead of msnake_step_tape")
     ap.add_argument("--no-rollout", action="store_true",
                     help="skip the secondary legs: msnake_rollout_tape, per_step_strided, selfplay_rollout (profiling)")
+    ap.add_argument("--preroll", type=int, default=1, help="untimed msnake_render launches queued ahead of each timed region's first event")
     ap.add_argument("--legs", default="tape,strided,selfplay", help="which secondary legs to run (comma list; --no-rollout = none)")
     ap.add_argument("--obs-scale", type=int, default=1, choices=[1, 4], help="4 = the fused 84x84x9 WarpFrame series (profiling; not the headline workload)")
     ap.add_argument("--epb", type=int, default=0, help="msnake_config.envs_per_block (0 = auto)")
@@ -298,7 +299,8 @@ def main():
         # that the event fires behind a running kernel and the K timed launches follow it back to back
         # as in the steady state; without it every region starts on an idle queue and pays one launch
         # latency (~10 us, i.e. 0.5 us per step at K = 20) inside the timed interval
-        env.render_device()
+        for _ in range(args.preroll):
+            env.render_device()
         ev0.record()
         run(K, Wm + r * K)
         ev1.record()
