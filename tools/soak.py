@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--keep", type=float, default=0.6, help="probability of action 0 (snakes live longer)")
     ap.add_argument("--obs-every", type=int, default=25)
     ap.add_argument("--max-steps", type=int, default=2000)
+    ap.add_argument("--tape", type=int, default=0, help="> 0: step through msnake_rollout_tape in chunks of this many steps (persistent kernel)")
     ap.add_argument("--store-policy", default="auto", choices=["auto", "plain", "stream"], help="plain = the aligned copy-out")
     args = ap.parse_args()
     import torch
@@ -35,15 +36,12 @@ def main():
     rs = np.random.default_rng(5)
     t0 = time.time()
     episodes = maxlen = 0
-    for t in range(args.steps):
-        act = rs.integers(0, 5, (n, ns)).astype(np.int32)
-        act = np.where(rs.random((n, ns)) < args.keep, 0, act).astype(np.int32)
-        obs_d, rew, done, info = env.step_device(torch.from_numpy(act).to(env.device))
-        want_obs = t % args.obs_every == 0 or t == args.steps - 1
+    def check(t, rew_h, done_h, info_h, obs_d, act):
+        nonlocal episodes
+        want_obs = obs_d is not None
         o_obs, o_rew, o_done, o_ns, o_er, o_el = ora.step(act, threads=16, want_obs=want_obs)
-        info_h = info.cpu().numpy()
-        assert np.array_equal(rew.cpu().numpy(), o_rew), t
-        assert np.array_equal(done.cpu().numpy(), o_done), t
+        assert np.array_equal(rew_h, o_rew), t
+        assert np.array_equal(done_h, o_done), t
         assert np.array_equal(info_h[:, 2], o_ns) and np.array_equal(info_h[:, 1], o_el), t
         assert np.array_equal(info_h[:, 0].copy().view(np.float32), o_er), t
         if want_obs:
@@ -51,6 +49,27 @@ def main():
         episodes += int(o_done.sum())
         if t % 500 == 0:
             print(f"step {t}: ok, episodes so far {episodes}, {time.time() - t0:.0f}s", flush=True)
+
+    def actions():
+        act = rs.integers(0, 5, (n, ns)).astype(np.int32)
+        return np.where(rs.random((n, ns)) < args.keep, 0, act).astype(np.int32)
+
+    if args.tape > 0:  # the persistent kernel: chunks of args.tape steps, every step's scalars, observations at obs-every
+        t = 0
+        while t < args.steps:
+            m = min(args.tape, args.steps - t)
+            acts = np.stack([actions() for _ in range(m)])
+            obs_t, rew_t, done_t, info_t = env.rollout_device(torch.from_numpy(acts).to(env.device))
+            rew_h, done_h, info_h = rew_t.cpu().numpy(), done_t.cpu().numpy(), info_t.cpu().numpy()
+            for j in range(m):
+                check(t + j, rew_h[j], done_h[j], info_h[j], obs_t[j] if ((t + j) % args.obs_every == 0 or t + j == args.steps - 1) else None, acts[j])
+            t += m
+    else:
+        for t in range(args.steps):
+            act = actions()
+            obs_d, rew, done, info = env.step_device(torch.from_numpy(act).to(env.device))
+            want_obs = t % args.obs_every == 0 or t == args.steps - 1
+            check(t, rew.cpu().numpy(), done.cpu().numpy(), info.cpu().numpy(), obs_d if want_obs else None, act)
     from oracle.snake_oracle import flat_to_state
     for e in range(0, n, max(1, n // 256)):
         st = flat_to_state(env.get_state_words(e))
@@ -58,7 +77,7 @@ def main():
         maxlen = max(maxlen, max(len(b) for b in st["snakes"]))
     st = env.stats()
     assert st["errors"] == 0 and st["episodes"] == episodes
-    print(f"SOAK OK: {args.rules} {n} envs x {args.steps} steps (store policy {args.store_policy}), {episodes} episodes, "
+    print(f"SOAK OK: {args.rules} {n} envs x {args.steps} steps (store policy {args.store_policy}, tape {args.tape}), {episodes} episodes, "
           f"longest body at the end {maxlen}, {time.time() - t0:.0f}s")
 
 
