@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Experiment: K per-step launches of msnake_step replayed from ONE captured HIP graph against the same
-launches issued directly (msnake_step_tape, C loop).   usage: graph_probe.py [envs] [steps per graph]"""
+launches issued directly (msnake_step_tape, C loop).   usage: graph_probe.py [envs] [steps per graph] [replays per timed region]"""
 import ctypes
 import os
 import sys
@@ -11,6 +11,7 @@ import msnake
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+REPS = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 NS = 3
 env = msnake.MultiSnakeVecEnv(n, dim=19, n_snakes=NS, seed=0, device="cuda:0")
 env.reset_device()
@@ -33,14 +34,13 @@ with torch.cuda.graph(g, stream=side):
 torch.cuda.synchronize()
 
 
-def timed(fn, reps=8):
+def timed(fn, reps=REPS):
     out = []
-    for _ in range(5):
+    for _ in range(9):
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(side):
-            env.render_device() if False else None
             e0.record(side)
             for _ in range(reps):
                 fn()
@@ -60,4 +60,4 @@ def replay():
         g.replay()
 
 
-print(f"{n} envs, {K} steps per graph: direct launches {timed(direct):.2f} us per step, graph replay {timed(replay):.2f} us per step")
+print(f"{n} envs, {K} steps per graph, {REPS} per timed region: direct launches {timed(direct):.2f} us per step, graph replay {timed(replay):.2f} us per step")
