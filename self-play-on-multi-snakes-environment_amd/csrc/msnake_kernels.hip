@@ -436,6 +436,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         // slow path only: keep the ten-round key schedule from being hoisted to kernel entry,
         // where it would pin 20 SGPRs for every wave
         asm volatile("" : "+s"(k0), "+s"(k1));
+#ifdef MSNAKE_DBG_STAGES
+        if (dbg & 0x4000) draws = ((ctr_lo + (uint32_t)lane) * 2654435761u) ^ ((uint32_t)gid * 40503u);  // stage bit 14: timing with a free Philox (wrong draws)
+        else
+#endif
         draws = philox_draws(ctr_lo, ctr_hi, lane, (uint32_t)gid, (uint32_t)(gid >> 32), k0, k1);
         draw_base = ctr_lo; draws_n = 64; refilled = true;
         SPAN_FLAG(4u);
@@ -528,6 +532,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // moved, i.e. without their popped tail (lane j of bf_pop) and with their new head (bf_nh).
     uint32_t bf_moved = 0, bf_pop = 0, bf_nh = 0;
     auto build_free = [&]() {
+#ifdef MSNAKE_DBG_STAGES
+        if (dbg & 0x2000) { nfree = n2; return; }  // stage bit 13: timing with a free free-cell map and pick (wrong cells)
+#endif
         uint8_t* occ = img + img_bytes;  // respawn occupancy (slow path: derived here, not held across the kernel)
         uint32_t* occw = reinterpret_cast<uint32_t*>(occ);
         for (int i = lane; i < ((n2 + 63) >> 6) * 2; i += 64) occw[i] = 0u;  // one bit per cell
@@ -563,11 +570,17 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         if (nfree > 0) {
             if (RULES == MSNAKE_RULES_ADVERSARIAL) ensure_draws(1);  // its respawn count is not known up front
             const uint32_t k = randint((uint32_t)nfree);
+#ifdef MSNAKE_DBG_STAGES
+            if (dbg & 0x2000) x = (int)k; else {
+#endif
             const int L = __builtin_ffsll((long long)ballot(freescan > k)) - 1;  // chunk holding the k-th free cell
             const uint64_t m = ((uint64_t)rdlane((uint32_t)(freemask >> 32), L) << 32) | rdlane((uint32_t)freemask, L);
             const uint32_t kk = k - (rdlane(freescan, L) - (uint32_t)__builtin_popcountll(m));
             const uint64_t sel = ballot(((m >> lane) & 1ull) && mbcnt(m) == kk);
             x = L * 64 + (__builtin_ffsll((long long)sel) - 1);
+#ifdef MSNAKE_DBG_STAGES
+            }
+#endif
         }
         // x / dim and x % dim without a division: pk2 carries M = floor(2^k / dim) + 1 with k = 14 + bits(dim),
         // exact for every x < 2^14 (cell indices stay below 63^2); the launch glue computes M

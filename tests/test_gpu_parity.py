@@ -477,6 +477,68 @@ def test_fuzz_long_bodies_against_oracle(rules):
     env.close()
 
 
+@pytest.mark.parametrize("dim", [7, 19])
+def test_respawn_with_and_without_shared_cells(dim):
+    """snake_env respawns take the map-free path (k-th free cell by rank over the body registers) only while no two
+    pieces share a cell; installed states whose bodies cross or stack must fall back to the occupancy map, and a
+    head that runs into a body, into another head or out of the grid in the very step it eats must be counted once.
+    Every env gets a fruit right in front of a moving head so that the first steps respawn."""
+    from oracle.snake_oracle import Oracle
+    rs = np.random.default_rng(4242 + dim)
+    n, ns = 192, 3
+    env = _mk(num_envs=n, dim=dim, n_snakes=ns, rules="snake_env", seed=5)
+    ora = Oracle(n, dim=dim, n_snakes=ns, n_fruits=ns, rules="snake_env", seed=5)
+    env.reset(); ora.reset()
+    step = {1: (1, 0), 2: (0, 1), 3: (-1, 0), 4: (0, -1)}
+    first = np.zeros((n, ns), np.int32)
+    for e in range(n):
+        kind = e % 4  # 0 disjoint, 1 bodies cross, 2 two snakes stacked on one cell, 3 a snake with one cell twice
+        snakes, vels = [], []
+        for j in range(ns):
+            ln = int(rs.integers(1, 6))
+            r = 1 + 2 * j if dim > 6 else j
+            c0 = int(rs.integers(ln, dim - 1))
+            snakes.append([[c0 - i, r] for i in range(ln)])  # head first, pointing to +c0
+            vels.append([1, 0])
+        if kind == 1:
+            snakes[1] = [[snakes[0][-1][0], snakes[0][-1][1] + 1 - i] for i in range(3)][::-1]  # a column through snake 0's tail
+            vels[1] = [0, 1]
+        elif kind == 2:
+            snakes[2] = [list(snakes[1][0])]
+            vels[2] = [0, 0]
+        elif kind == 3 and len(snakes[0]) > 1:
+            snakes[0] = snakes[0] + [list(snakes[0][-1])]  # (tail cell twice; a body crossing its own HEAD cell cannot be rendered in the reference)
+        fruits = []
+        for j in range(ns):
+            a = int(rs.integers(1, 5))
+            first[e, j] = a if rs.random() < 0.8 else 0
+            v = step[a] if first[e, j] else tuple(vels[j])
+            if v == (-vels[j][0], -vels[j][1]) or v == (0, 0):
+                v = tuple(vels[j])  # a reversal is ignored: the snake keeps going
+            h = snakes[j][0]
+            fc = [h[0] + v[0], h[1] + v[1]] if rs.random() < 0.85 else [int(rs.integers(0, dim)), int(rs.integers(0, dim))]
+            fruits.append([min(max(fc[0], 0), dim - 1), min(max(fc[1], 0), dim - 1)])
+        st = {"snakes": snakes, "fruits": fruits, "vels": vels, "grow_to": [len(b) + int(rs.integers(0, 3)) for b in snakes],
+              "t": int(rs.integers(0, 50)), "ctr": int(rs.integers(0, 500)), "alive": [True] * ns, "in_dead": [False] * ns, "spare_fruits": 0}
+        _set_state(env, e, st); ora.set_state(e, st)
+    assert np.array_equal(env.render(), ora.render())
+    ate = 0
+    for t in range(24):
+        act = first if t == 0 else rs.integers(0, 5, (n, ns)).astype(np.int32)
+        obs, rew, done, infos = env.step(act)
+        o_obs, o_rew, o_done, o_ns, o_er, o_el = ora.step(act)
+        ate += int((o_rew > 0).sum())
+        assert np.array_equal(rew, o_rew) and np.array_equal(done, o_done.astype(bool)), t
+        assert np.array_equal(infos._ns, o_ns) and np.array_equal(infos._l, o_el), t
+        assert np.array_equal(obs, o_obs), t
+        if t in (0, 1, 5):
+            for e in range(n):
+                assert _state(env, e) == ora.get_state(e), (t, e)
+    assert ate > n // 4  # the set-up did produce respawns
+    assert env.stats()["errors"] == 0
+    env.close()
+
+
 @pytest.mark.parametrize("dim,ns,nf,rules", [(2, 1, 1, "snake_env"), (3, 2, 2, "snake_env"), (5, 3, 3, "adversarial"),
                                               (30, 3, 3, "snake_env"), (62, 3, 3, "snake_env"), (62, 4, 32, "new_world"),
                                               (45, 4, 0, "new_world"), (7, 1, 9, "new_world")])

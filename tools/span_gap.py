@@ -104,6 +104,14 @@ for rep in range(5):
                                   "copy_out": stage(painted, issued), "ack": stage(issued, acked)},
         "by_class": {"fast_path": cls((flags & 0xF) == 0), "ate": cls((flags & 1) != 0), "episode_end": cls((flags & 2) != 0),
                      "philox_ahead_of_logic": cls(((flags & 4) != 0) & ((flags & 8) == 0)), "late_refill": cls((flags & 8) != 0)},
+        # what the slow paths cost the launch: its span counted over the fast-path waves only
+        "span_over_fast_path_waves_us": {"median": round(float(np.median(np.where((flags & 0xF) == 0, rel_end, 0).max(1))), 3),
+                                         "vs_all_waves_median": round(float(np.median(rel_end.max(1) - np.where((flags & 0xF) == 0, rel_end, 0).max(1))), 3)},
+        "fast_path_life_us": {"p99": pct(life[(flags & 0xF) == 0], 99), "p999": pct(life[(flags & 0xF) == 0], 99.9)},
+        # least squares over all waves of the region: life = base + a*[ate] + b*[episode end] + c*[Philox ahead of the logic]
+        "life_fit_us": dict(zip(("base", "ate", "episode_end", "philox"), [round(float(x), 3) for x in np.linalg.lstsq(
+            np.stack([np.ones(life.size), ((flags & 1) != 0).ravel(), ((flags & 2) != 0).ravel(), (((flags & 4) != 0) & ((flags & 8) == 0)).ravel()], 1).astype(np.float64),
+            life.ravel().astype(np.float64), rcond=None)[0]])),
         "last_32_finishers_per_launch": tail,
         "last_ack_per_xcd_us_since_launch_start": per_xcd,
     })
