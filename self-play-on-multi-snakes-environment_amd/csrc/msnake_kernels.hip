@@ -389,14 +389,6 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // (every lane loads -- lanes >= NS re-read the last snake's action, which nothing looks at -- instead of
     //  an exec-mask region around three lanes)
     if (MODE == 0) actv = actions[(uint32_t)e * (uint32_t)action_stride + (uint32_t)(lane < NS ? lane : NS - 1)];
-    // Early Philox (per-step launches with parked draws): the draw counter and the state of the parked draws also come
-    // by two SCALAR loads, which land before the background has, so that a wave whose parked draws no longer cover a
-    // reset (4*NS) evaluates Philox while it waits for its loads instead of ahead of its logic when the reset comes.
-    constexpr bool EARLY_PHILOX = MODE == 0 && RULES != MSNAKE_RULES_NEW_WORLD;
-    unsigned long long early_ctr = 0, early_pc = 0;
-    if (EARLY_PHILOX && !short_rec)
-        asm volatile("s_load_dwordx2 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4"
-                     : "=&s"(early_ctr), "=&s"(early_pc) : "s"(hdr_g), "n"(HDR_CTR_LO * 4), "n"(HDR_PC_VALID * 4) : "memory");
     // (the state loads above are in flight before anything else of the entry block is computed)
     __builtin_amdgcn_sched_barrier(0);
     lds_layout();
@@ -745,36 +737,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #undef MSNAKE_GP
 #undef MSNAKE_LP
     }
-    // early Philox: lane l >= HDR_PC_FIRST computes draw ctr + (l - HDR_PC_FIRST), i.e. the word it will park
-    uint32_t early = 0;
-    bool early_ok = false;
-    if (EARLY_PHILOX && !short_rec) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(early_ctr), "+s"(early_pc));
-        const uint32_t c_lo = (uint32_t)early_ctr, c_hi = (uint32_t)(early_ctr >> 32);
-        const uint32_t pv = (uint32_t)early_pc, pb = (uint32_t)(early_pc >> 32);
-        // fewer than 4*NS parked draws left (or none parked), and not within reach of the 2^32 wrap of the low word
-        early_ok = (pv != 1u || c_lo - pb > (uint32_t)(HDR_PC_N - 4 * NS)) && c_lo < 0xFFFFFF00u;
-        if (early_ok) {
-            uint32_t ee = (uint32_t)e;
-            asm volatile("" : "+s"(ee));
-            const uint64_t gid = p.env_id_base + (uint64_t)ee;
-            uint32_t k0 = p.seed_lo, k1 = p.seed_hi;
-            asm volatile("" : "+s"(k0), "+s"(k1));
-            const uint32_t b_lo = c_lo - (uint32_t)HDR_PC_FIRST, b_hi = c_hi - (c_lo < (uint32_t)HDR_PC_FIRST ? 1u : 0u);
-            early = philox_draws(b_lo, b_hi, lane, (uint32_t)gid, (uint32_t)(gid >> 32), k0, k1);
-            SPAN_FLAG(8u);
-        }
-    }
     // every load issued so far (state, actions, background) has landed past this point: the env
     // logic needs the state right away, and the painters must find the background in LDS.  In MODES
     // 0-2 no store has been issued yet, so this waits for loads only.
     if (!LDSBG || (step_i & 15) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (EARLY_PHILOX && early_ok) {  // the fresh draws are parked at once: whatever needs draws in this step finds them there
-        hv = lane >= HDR_PC_FIRST ? early : hv;
-        HV_SET_C(HDR_PC_BASE, (uint32_t)early_ctr);
-        HV_SET_C(HDR_PC_VALID, 1u);
-        if (UPPER_TRACKED) upper_dirty = true;
-    }
     // (the ring slots arrive zero-extended; hiding that they were 16-bit loads spares a v_and per snake)
 #pragma unroll
     for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(cr[s]));
