@@ -79,7 +79,7 @@ constexpr int DPP_IDENTITY = 0xE4;  // quad_perm:[0,1,2,3]
 // lane compares straight to a 64-bit lane mask (v_cmp into an SGPR pair), and a lane mask back to a
 // per-lane predicate without an instruction: `ballot(b)` of a bool that also has other uses costs a
 // v_cndmask + v_cmp pair, `(mask >> lane) & 1` a shift, an and and a compare
-constexpr int CMP_EQ = 32, CMP_NE = 33, CMP_UGE = 35, CMP_ULT = 36;
+constexpr int CMP_EQ = 32, CMP_NE = 33, CMP_UGT = 34, CMP_UGE = 35, CMP_ULT = 36;
 template <int PRED>
 __device__ __forceinline__ uint64_t lanes_where(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, PRED); }
 __device__ __forceinline__ bool in_mask(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
@@ -531,6 +531,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // [S] respawns run AHEAD of the vector move (section 1a): snakes in `bf_moved` count as already
     // moved, i.e. without their popped tail (lane j of bf_pop) and with their new head (bf_nh).
     uint32_t bf_moved = 0, bf_pop = 0, bf_nh = 0;
+    // the same for the straight-line form of the map (every body within its 64-slot ring): lane j = the number of
+    // pieces of snake j that count at this moment (its length, less the popped tail if it has moved)
+    uint32_t bf_len = 0;
+    bool bf_short = false;
     auto build_free = [&]() {
 #ifdef MSNAKE_DBG_STAGES
         if (dbg & 0x2000) { nfree = n2; return; }  // stage bit 13: timing with a free free-cell map and pick (wrong cells)
@@ -544,6 +548,16 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             const int used = ((int)(cell & 255u) - 1) * dim + ((int)(cell >> 8) - 1);
             if ((uint32_t)used < (uint32_t)n2) atomicOr(&occw[used >> 5], 1u << (used & 31));
         };
+        if (RULES == MSNAKE_RULES_SNAKE_ENV && bf_short) {
+            // straight-line form (section 1a, no body beyond its ring): the new heads of the snakes already moved go in
+            // by ONE masked store (lane j = snake j), each body by one more
+            if (in_mask((uint64_t)bf_moved)) mark(0, bf_nh);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const uint32_t pi = (uint32_t)(lane - (int)(rdlane(hv, SN_C(j)) >> SN_C_HP0_SHIFT)) & 63u;
+                if (pi < rdlane(bf_len, j)) mark(0, cr[j]);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const uint32_t w0 = rdlane(hv, SN_A(j));
@@ -553,6 +567,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 if (lane == 0) mark(0, rdlane(bf_nh, j));
             }
             for_each_piece(j, cr[j], w0, rdlane(hv, SN_C(j)), len, mark);
+        }
         }
         wave_sync();
         const int base = lane * 64;
@@ -824,12 +839,14 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             //      the current fruit positions), which is what re-deriving bit f of the later lanes'
             //      eat masks reproduces.
             bf_nh = (uint32_t)v_nh;
+            bf_short = ((uint32_t)lanes_where<CMP_UGT>((uint32_t)v_len, 64u) & (uint32_t)NSMASK) == 0;
 #pragma nounroll
             for (int s = 0; s < NS; ++s) {
                 uint32_t m = rdlane(v_em, s);
                 if (m == 0) continue;
                 bf_pop = (v_moves && v_len >= v_grow + 2 * __builtin_popcount(v_em)) ? 1u : 0u;  // lanes <= s are final
                 bf_moved = (uint32_t)mvmask & ((2u << s) - 1u);
+                bf_len = (uint32_t)v_len - (in_mask((uint64_t)bf_moved) ? bf_pop : 0u);
                 STAMP2(0);
                 ensure_draws((uint32_t)__builtin_popcount(m));
                 STAMP2(1);
