@@ -389,6 +389,14 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // (every lane loads -- lanes >= NS re-read the last snake's action, which nothing looks at -- instead of
     //  an exec-mask region around three lanes)
     if (MODE == 0) actv = actions[(uint32_t)e * (uint32_t)action_stride + (uint32_t)(lane < NS ? lane : NS - 1)];
+    // Early Philox (per-step launches with parked draws): the draw counter and the state of the parked draws also come
+    // by two SCALAR loads, which land before the background has, so that a wave whose parked draws no longer cover a
+    // reset (4*NS) evaluates Philox while it waits for its loads instead of ahead of its logic when the reset comes.
+    constexpr bool EARLY_PHILOX = MODE == 0 && RULES != MSNAKE_RULES_NEW_WORLD;
+    unsigned long long early_ctr = 0, early_pc = 0;
+    if (EARLY_PHILOX && !short_rec)
+        asm volatile("s_load_dwordx2 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4"
+                     : "=&s"(early_ctr), "=&s"(early_pc) : "s"(hdr_g), "n"(HDR_CTR_LO * 4), "n"(HDR_PC_VALID * 4) : "memory");
     // (the state loads above are in flight before anything else of the entry block is computed)
     __builtin_amdgcn_sched_barrier(0);
     lds_layout();
@@ -580,11 +588,20 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         nfree = (int)rdlane(freescan, 63);
         wave_sync();
     };
-    auto safe_cell = [&]() -> uint32_t {
+    // the draw that is parked in the record for the current counter, straight out of the record register (the caller
+    // has checked: parked draws valid, counter within them, no Philox evaluation cached in `draws`)
+    auto randint_parked = [&](uint32_t n) -> uint32_t {
+        const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
+        const uint32_t u = rdlane(hv, (int)((uint32_t)HDR_PC_FIRST + ctr_lo - rdlane(hv, HDR_PC_BASE)));
+        const uint32_t nlo = ctr_lo + 1;
+        HV_SET_C(HDR_CTR_LO, nlo);
+        if (nlo == 0) ctr_wrapped(ctr_hi);
+        return (uint32_t)(((uint64_t)u * n) >> 32);
+    };
+    auto pick_cell = [&](auto&& rnd) -> uint32_t {
         int x = 0;
         if (nfree > 0) {
-            if (RULES == MSNAKE_RULES_ADVERSARIAL) ensure_draws(1);  // its respawn count is not known up front
-            const uint32_t k = randint((uint32_t)nfree);
+            const uint32_t k = rnd((uint32_t)nfree);
 #ifdef MSNAKE_DBG_STAGES
             if (dbg & 0x2000) x = (int)k; else {
 #endif
@@ -605,6 +622,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         const uint32_t q = ((uint32_t)x * (p2 >> PK2_DIVM_SHIFT)) >> sh;
         const uint32_t r = (uint32_t)x - q * (uint32_t)dim;
         return ((r + 1u) << 8) | (q + 1u);
+    };
+    auto safe_cell = [&]() -> uint32_t {
+        if (RULES == MSNAKE_RULES_ADVERSARIAL && nfree > 0) ensure_draws(1);  // its respawn count is not known up front
+        return pick_cell(randint);
     };
 
     // ---- reset: [S]:219-232 / [NE]:27-33 -> [N]:55-73 ------------------------------------------
@@ -752,10 +773,36 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #undef MSNAKE_GP
 #undef MSNAKE_LP
     }
+    // early Philox: lane l >= HDR_PC_FIRST computes draw ctr + (l - HDR_PC_FIRST), i.e. the word it will park
+    uint32_t early = 0;
+    bool early_ok = false;
+    if (EARLY_PHILOX && !short_rec) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(early_ctr), "+s"(early_pc));
+        const uint32_t c_lo = (uint32_t)early_ctr, c_hi = (uint32_t)(early_ctr >> 32);
+        const uint32_t pv = (uint32_t)early_pc, pb = (uint32_t)(early_pc >> 32);
+        // fewer than 4*NS parked draws left (or none parked), and not within reach of the 2^32 wrap of the low word
+        early_ok = (pv != 1u || c_lo - pb > (uint32_t)(HDR_PC_N - 4 * NS)) && c_lo < 0xFFFFFF00u;
+        if (early_ok) {
+            uint32_t ee = (uint32_t)e;
+            asm volatile("" : "+s"(ee));
+            const uint64_t gid = p.env_id_base + (uint64_t)ee;
+            uint32_t k0 = p.seed_lo, k1 = p.seed_hi;
+            asm volatile("" : "+s"(k0), "+s"(k1));
+            const uint32_t b_lo = c_lo - (uint32_t)HDR_PC_FIRST, b_hi = c_hi - (c_lo < (uint32_t)HDR_PC_FIRST ? 1u : 0u);
+            early = philox_draws(b_lo, b_hi, lane, (uint32_t)gid, (uint32_t)(gid >> 32), k0, k1);
+            SPAN_FLAG(8u);
+        }
+    }
     // every load issued so far (state, actions, background) has landed past this point: the env
     // logic needs the state right away, and the painters must find the background in LDS.  In MODES
     // 0-2 no store has been issued yet, so this waits for loads only.
     if (!LDSBG || (step_i & 15) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (EARLY_PHILOX && early_ok) {  // the fresh draws are parked at once: whatever needs draws in this step finds them there
+        hv = lane >= HDR_PC_FIRST ? early : hv;
+        HV_SET_C(HDR_PC_BASE, (uint32_t)early_ctr);
+        HV_SET_C(HDR_PC_VALID, 1u);
+        if (UPPER_TRACKED) upper_dirty = true;
+    }
     // (the ring slots arrive zero-extended; hiding that they were 16-bit loads spares a v_and per snake)
 #pragma unroll
     for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(cr[s]));
@@ -840,8 +887,32 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             //      eat masks reproduces.
             bf_nh = (uint32_t)v_nh;
             bf_short = ((uint32_t)lanes_where<CMP_UGT>((uint32_t)v_len, 64u) & (uint32_t)NSMASK) == 0;
+            // The usual case in straight-line code: ONE snake eats ONE fruit, every body within its ring, the draw parked
+            // in the record.  Anything else -- and whatever a later snake eats off the respawned fruit -- takes the loop.
+            int s_begin = 0;
+            {
+                const uint32_t eaters = (uint32_t)lanes_where<CMP_NE>(v_em, 0u) & (uint32_t)NSMASK;
+                const int s1 = __builtin_ctz(eaters | (1u << NS));
+                const uint32_t m1 = rdlane(v_em, s1);
+                const uint32_t pc_at = rdlane(hv, HDR_CTR_LO) - rdlane(hv, HDR_PC_BASE);
+                if (eaters != 0 && (eaters & (eaters - 1u)) == 0 && (m1 & (m1 - 1u)) == 0 && bf_short && PCACHE && !refilled &&
+                    rdlane(hv, HDR_PC_VALID) == 1u && pc_at < (uint32_t)HDR_PC_N) {
+                    bf_pop = (v_moves && v_len >= v_grow + 2 * __builtin_popcount(v_em)) ? 1u : 0u;
+                    bf_moved = (uint32_t)mvmask & ((2u << s1) - 1u);
+                    bf_len = (uint32_t)v_len - (in_mask((uint64_t)bf_moved) ? bf_pop : 0u);
+                    build_free();
+                    const int f = __builtin_ctz(m1 | (1u << NS));
+                    const uint32_t c = pick_cell(randint_parked);
+                    HV_SET_DYN(FR0 + f, c);
+                    const uint32_t bit = (uint32_t)v_nh == c ? (1u << f) : 0u;
+                    v_em = (v_moves && lane > s1) ? ((v_em & ~(1u << f)) | bit) : v_em;
+                    s_begin = s1 + 1;
+                    // (a later snake whose new head is where the fruit went eats it in this step: the loop below finds it)
+                    if (((uint32_t)lanes_where<CMP_NE>(v_em, 0u) & (uint32_t)NSMASK & ~((2u << s1) - 1u)) == 0) s_begin = NS;
+                }
+            }
 #pragma nounroll
-            for (int s = 0; s < NS; ++s) {
+            for (int s = s_begin; s < NS; ++s) {
                 uint32_t m = rdlane(v_em, s);
                 if (m == 0) continue;
                 bf_pop = (v_moves && v_len >= v_grow + 2 * __builtin_popcount(v_em)) ? 1u : 0u;  // lanes <= s are final
