@@ -460,10 +460,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         if (PCACHE && !refilled && need <= HDR_PC_N && rdlane(hv, HDR_PC_VALID) == 1u) {
             const uint32_t pb = rdlane(hv, HDR_PC_BASE);
             if (ctr_lo - pb <= HDR_PC_N - need) {
-                int l2 = lane;
-                asm volatile("" : "+v"(l2));  // (keeps the lane arithmetic of this slow path out of the kernel's entry block)
-                draws = (uint32_t)__shfl((int)hv, l2 + HDR_PC_FIRST);  // lane l <- record word 37 + l
-                draw_base = pb; draws_n = HDR_PC_N;
+                // the record register itself serves as the cache: draw PC_BASE + i sits in lane HDR_PC_FIRST + i, i.e.
+                // "64 draws from PC_BASE - HDR_PC_FIRST on" of which only the parked ones are ever asked for (no shuffle)
+                draws = hv;
+                draw_base = pb - (uint32_t)HDR_PC_FIRST; draws_n = (uint32_t)(HDR_PC_FIRST + HDR_PC_N);
                 return;
             }
         }
