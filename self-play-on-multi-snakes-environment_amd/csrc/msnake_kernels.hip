@@ -390,7 +390,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     //  an exec-mask region around three lanes)
     if (MODE == 0) actv = actions[(uint32_t)e * (uint32_t)action_stride + (uint32_t)(lane < NS ? lane : NS - 1)];
     // Early Philox (per-step launches with parked draws): the draw counter and the state of the parked draws also come
-    // by two SCALAR loads, which land before the background has, so that a wave whose parked draws no longer cover a
+    // by two SCALAR loads, which land before the background has (issued AHEAD of the state loads they cost every wave 0.03 us), so that a wave whose parked draws no longer cover a
     // reset (4*NS) evaluates Philox while it waits for its loads instead of ahead of its logic when the reset comes.
     constexpr bool EARLY_PHILOX = MODE == 0 && RULES != MSNAKE_RULES_NEW_WORLD;
     unsigned long long early_ctr = 0, early_pc = 0;
@@ -549,7 +549,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #endif
         uint8_t* occ = img + img_bytes;  // respawn occupancy (slow path: derived here, not held across the kernel)
         uint32_t* occw = reinterpret_cast<uint32_t*>(occ);
-        for (int i = lane; i < ((n2 + 63) >> 6) * 2; i += 64) occw[i] = 0u;  // one bit per cell
+        // one bit per cell, 64 of them per lane of the readback below
+        if (n2 <= 2048) { if (lane < ((n2 + 63) >> 6) * 2) occw[lane] = 0u; }
+        else for (int i = lane; i < ((n2 + 63) >> 6) * 2; i += 64) occw[i] = 0u;
         wave_sync();
         auto mark = [&](int, uint32_t cell) {
             // used = c1*dim + c0; out-of-grid heads alias onto other cells or fall outside
@@ -637,10 +639,15 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         if (RULES != MSNAKE_RULES_NEW_WORLD) {
             // [S]:223-225 draws snake s's cell then fruit s's cell, each (randint(dim), randint(dim)):
             // 4*NS consecutive draws.  All of them at once: lane l takes draw ctr + l.
-            ensure_draws(4u * NS);
             const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
-            const uint32_t idx0 = ctr_lo - draw_base;
-            const uint32_t u = (uint32_t)__shfl((int)draws, (int)idx0 + lane);
+            const uint32_t pc_at = ctr_lo - rdlane(hv, HDR_PC_BASE);
+            uint32_t u;
+            if (PCACHE && !refilled && rdlane(hv, HDR_PC_VALID) == 1u && pc_at <= (uint32_t)(HDR_PC_N - 4 * NS)) {
+                u = (uint32_t)__shfl((int)hv, (int)((uint32_t)HDR_PC_FIRST + pc_at) + lane);  // the usual case: parked draws, in place
+            } else {
+                ensure_draws(4u * NS);
+                u = (uint32_t)__shfl((int)draws, (int)(ctr_lo - draw_base) + lane);
+            }
             const uint32_t v = (uint32_t)(((uint64_t)u * (uint32_t)dim) >> 32) + 1u;  // padded coordinate
             const uint32_t cellv = (v << 8) | row_shl<1>(0u, v);                     // even lanes: (c0+1, c1+1)
             hv = lane < NS ? (1u << 16) : hv;                    // SN_A: overflow empty, len 1
