@@ -392,7 +392,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // Early Philox (per-step launches with parked draws): the draw counter and the state of the parked draws also come
     // by two SCALAR loads, which land before the background has (issued AHEAD of the state loads they cost every wave 0.03 us), so that a wave whose parked draws no longer cover a
     // reset (4*NS) evaluates Philox while it waits for its loads instead of ahead of its logic when the reset comes.
-    constexpr bool EARLY_PHILOX = MODE == 0 && RULES != MSNAKE_RULES_NEW_WORLD;
+    // (snake_env only: the adversarial per-step kernels have no SGPRs to spare for it -- 5 spilled instead of 2)
+    constexpr bool EARLY_PHILOX = MODE == 0 && RULES == MSNAKE_RULES_SNAKE_ENV;
     unsigned long long early_ctr = 0, early_pc = 0;
     if (EARLY_PHILOX && !short_rec)
         asm volatile("s_load_dwordx2 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4"
