@@ -428,7 +428,10 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     //      the record's cache words (HDR_PC_*), 0 = none.
     constexpr bool PCACHE = RULES != MSNAKE_RULES_NEW_WORLD;  // new_world's fruits may fill the record
     uint32_t draws = 0, draw_base = 0, draws_n = 0;
-    bool refilled = false;
+    // 0: no Philox evaluation is cached in `draws`; 1: one is, and what it leaves is parked at the end of the step; 2: one is,
+    // short record (nowhere to park).  (Wave-uniform flags are kept as NUMBERS: as bools they become 64-bit lane masks, and
+    // every test of a combination of them is a handful of scalar instructions on this kernel's busiest port.)
+    uint32_t refilled = 0;
 #ifdef MSNAKE_LATE_REFILL
     uint32_t slow_step = 0;  // != 0: this wave respawned a fruit or ended an episode in this launch (MODE 0 / 1)
 #endif
@@ -436,7 +439,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // that change it (a Philox evaluation, the 2^32-draw wrap), not in every one.  (new_world keeps its fruits
     // there; the adversarial kernels have no SGPR to spare for the flag.)
     constexpr bool UPPER_TRACKED = RULES == MSNAKE_RULES_SNAKE_ENV;
-    bool upper_dirty = !UPPER_TRACKED;
+    // words of the record beyond the first 32 that go back to memory at the end of the step (0 or 32; a number, see `refilled`)
+    uint32_t rec_extra = (UPPER_TRACKED || short_rec) ? 0u : (uint32_t)(MSNAKE_HDR_WORDS - MSNAKE_HDR_SHORT_WORDS);
+    auto upper_is_dirty = [&]() { if (UPPER_TRACKED) rec_extra = short_rec ? 0u : (uint32_t)(MSNAKE_HDR_WORDS - MSNAKE_HDR_SHORT_WORDS); };
     auto refill_draws = [&](uint32_t ctr_lo, uint32_t ctr_hi) {
         uint32_t ee = (uint32_t)e;
         asm volatile("" : "+s"(ee));  // (slow path only, like the key schedule below)
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         else
 #endif
         draws = philox_draws(ctr_lo, ctr_hi, lane, (uint32_t)gid, (uint32_t)(gid >> 32), k0, k1);
-        draw_base = ctr_lo; draws_n = 64; refilled = true;
+        draw_base = ctr_lo; draws_n = 64; refilled = short_rec ? 2u : 1u;
         SPAN_FLAG(4u);
     };
     // the next `need` (<= 64) draws are cached afterwards.  Callers run this BEFORE they build
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     auto ensure_draws = [&](uint32_t need) {
         const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
         if (need <= draws_n && ctr_lo - draw_base <= draws_n - need) return;
-        if (PCACHE && !refilled && need <= HDR_PC_N && rdlane(hv, HDR_PC_VALID) == 1u) {
+        if (PCACHE && refilled == 0 && need <= HDR_PC_N && rdlane(hv, HDR_PC_VALID) == 1u) {
             const uint32_t pb = rdlane(hv, HDR_PC_BASE);
             if (ctr_lo - pb <= HDR_PC_N - need) {
                 // the record register itself serves as the cache: draw PC_BASE + i sits in lane HDR_PC_FIRST + i, i.e.
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     auto ctr_wrapped = [&](uint32_t ctr_hi) {  // once per 2^32 draws: drop both caches
         HV_SET_C(HDR_CTR_HI, ctr_hi + 1);
         draws_n = 0;
-        if (PCACHE) { HV_SET_C(HDR_PC_VALID, 0u); if (UPPER_TRACKED) upper_dirty = true; }
+        if (PCACHE) { HV_SET_C(HDR_PC_VALID, 0u); upper_is_dirty(); }
     };
     auto randint = [&](uint32_t n) -> uint32_t {  // ensure_draws() has covered this draw
         const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
@@ -643,7 +648,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO), ctr_hi = rdlane(hv, HDR_CTR_HI);
             const uint32_t pc_at = ctr_lo - rdlane(hv, HDR_PC_BASE);
             uint32_t u;
-            if (PCACHE && !refilled && rdlane(hv, HDR_PC_VALID) == 1u && pc_at <= (uint32_t)(HDR_PC_N - 4 * NS)) {
+            if (PCACHE && refilled == 0 && rdlane(hv, HDR_PC_VALID) == 1u && pc_at <= (uint32_t)(HDR_PC_N - 4 * NS)) {
                 u = (uint32_t)__shfl((int)hv, (int)((uint32_t)HDR_PC_FIRST + pc_at) + lane);  // the usual case: parked draws, in place
             } else {
                 ensure_draws(4u * NS);
@@ -783,14 +788,21 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     }
     // early Philox: lane l >= HDR_PC_FIRST computes draw ctr + (l - HDR_PC_FIRST), i.e. the word it will park
     uint32_t early = 0;
-    bool early_ok = false;
+    // (the test every wave makes is kept to integer arithmetic and ONE compare: written with bools it compiles to a dozen
+    //  scalar select / and instructions and four branches, and the scalar unit is this kernel's busiest port -- an extra
+    //  scalar instruction per wave costs a launch 7.5 ns, MSNAKE_PAD_SALU below)
+    uint32_t early_ok = 0;
     if (EARLY_PHILOX && !short_rec) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(early_ctr), "+s"(early_pc));
         const uint32_t c_lo = (uint32_t)early_ctr, c_hi = (uint32_t)(early_ctr >> 32);
         const uint32_t pv = (uint32_t)early_pc, pb = (uint32_t)(early_pc >> 32);
-        // fewer than 4*NS parked draws left (or none parked), and not within reach of the 2^32 wrap of the low word
-        early_ok = (pv != 1u || c_lo - pb > (uint32_t)(HDR_PC_N - 4 * NS)) && c_lo < 0xFFFFFF00u;
-        if (early_ok) {
+        // fewer than 4*NS parked draws left, or none parked (HDR_PC_VALID is 0 or 1) ...
+        uint32_t used = (c_lo - pb) | ((pv ^ 1u) << 5);
+        asm volatile("" : "+s"(used));
+        // (parked draws may straddle the 2^32 wrap of the counter's low word: lane arithmetic is 64 bit, and crossing the
+        //  wrap drops the parked draws -- ctr_wrapped -- before any of them could be taken for the wrong counter)
+        if (used > (uint32_t)(HDR_PC_N - 4 * NS)) {
+            early_ok = 1u;
             uint32_t ee = (uint32_t)e;
             asm volatile("" : "+s"(ee));
             const uint64_t gid = p.env_id_base + (uint64_t)ee;
@@ -805,11 +817,34 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // logic needs the state right away, and the painters must find the background in LDS.  In MODES
     // 0-2 no store has been issued yet, so this waits for loads only.
     if (!LDSBG || (step_i & 15) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (EARLY_PHILOX && early_ok) {  // the fresh draws are parked at once: whatever needs draws in this step finds them there
+#if defined(MSNAKE_PAD_SALU) || defined(MSNAKE_PAD_VALU) || defined(MSNAKE_PAD_BRANCH)
+    // experiment (tools: make variant NAME=pads EXTRA=-DMSNAKE_PAD_SALU=32): what one more scalar / vector / branch instruction per
+    // wave costs a launch -- 7.5 ns per scalar instruction (16 env-waves per CU share ONE scalar port), 1.6 ns per vector one
+    {
+#ifdef MSNAKE_PAD_SALU
+        uint32_t pad = pk0v;
+#pragma unroll
+        for (int i = 0; i < MSNAKE_PAD_SALU; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(pad) :: "scc");
+        if (pad == 0xDEADBEEFu) hv = pad;
+#endif
+#ifdef MSNAKE_PAD_VALU
+        uint32_t padv = (uint32_t)lane;
+#pragma unroll
+        for (int i = 0; i < MSNAKE_PAD_VALU; ++i) asm volatile("v_add_u32 %0, %0, 1" : "+v"(padv));
+        if (padv == 0xDEADBEEFu) hv = padv;
+#endif
+#ifdef MSNAKE_PAD_BRANCH
+#pragma unroll
+        for (int i = 0; i < MSNAKE_PAD_BRANCH; ++i) asm volatile("s_cmp_eq_u32 0, 1\n\ts_cbranch_scc1 1f\n\ts_nop 0\n1:" ::: "scc");
+#endif
+    }
+#endif
+    asm volatile("" : "+s"(early_ok));
+    if (EARLY_PHILOX && early_ok != 0) {  // the fresh draws are parked at once: whatever needs draws in this step finds them there
         hv = lane >= HDR_PC_FIRST ? early : hv;
         HV_SET_C(HDR_PC_BASE, (uint32_t)early_ctr);
         HV_SET_C(HDR_PC_VALID, 1u);
-        if (UPPER_TRACKED) upper_dirty = true;
+        upper_is_dirty();
     }
     // (the ring slots arrive zero-extended; hiding that they were 16-bit loads spares a v_and per snake)
 #pragma unroll
@@ -903,7 +938,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 const int s1 = __builtin_ctz(eaters | (1u << NS));
                 const uint32_t m1 = rdlane(v_em, s1);
                 const uint32_t pc_at = rdlane(hv, HDR_CTR_LO) - rdlane(hv, HDR_PC_BASE);
-                if (eaters != 0 && (eaters & (eaters - 1u)) == 0 && (m1 & (m1 - 1u)) == 0 && bf_short && PCACHE && !refilled &&
+                if (eaters != 0 && (eaters & (eaters - 1u)) == 0 && (m1 & (m1 - 1u)) == 0 && bf_short && PCACHE && refilled == 0 &&
                     rdlane(hv, HDR_PC_VALID) == 1u && pc_at < (uint32_t)HDR_PC_N) {
                     bf_pop = (v_moves && v_len >= v_grow + 2 * __builtin_popcount(v_em)) ? 1u : 0u;
                     bf_moved = (uint32_t)mvmask & ((2u << s1) - 1u);
@@ -1354,6 +1389,14 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
 #ifdef MSNAKE_DBG_STAGES
         if (dbg == 6) asm volatile("s_endpgm");
 #endif
+#if defined(MSNAKE_PAD_SALU_COPYOUT)
+        {   // (the same experiment at the start of the copy-out)
+            uint32_t pad = pk0v;
+#pragma unroll
+            for (int i = 0; i < MSNAKE_PAD_SALU_COPYOUT; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(pad) :: "scc");
+            if (pad == 0xDEADBEEFu) hv = pad;
+        }
+#endif
         if (align_now) {
             // ---- 7a. aligned copy-out (per-step launches; tapes whose step stride is a multiple of 16 bytes): LDS byte x of the buffer <-> global byte g_al + x, both sides
             //          16-byte aligned; wave instruction i covers the i-th KiB counted from the 128-byte line the image
@@ -1397,10 +1440,14 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             };
             if (pk2 & (MODE == 3 ? PK2_STREAM_TAPE : PK2_STREAM_OBS)) chunks(std::true_type{});
             else chunks(std::false_type{});
-            // head bytes [shift, 16) on lanes 0..15 (when shift > 0), tail bytes [end & ~15, end) on lanes 16..31
-            const int byte = lane < 16 ? lane : (end & ~15) + (lane - 16);
-            const bool on = lane < 16 ? (obs_shift != 0 && lane >= (int)obs_shift && lane < end) : (lane < 32 && byte < end && byte >= 16);
-            if (on) g_al[byte] = img[byte];
+            // head bytes [shift, 16) on lanes 0..15 (when shift > 0), tail bytes [end & ~15, end) on lanes 16..31: lane l is on
+            // iff l - first < count with (first, count) = (shift, (16 - shift) & 15) resp. (16, end & 15) -- vector selects and ONE
+            // compare (as a chain of bools this predicate was 17 scalar mask instructions; images are at least 32 bytes long)
+            const bool head = lane < 16;
+            const int byte = head ? lane : (end & ~15) + (lane - 16);
+            const uint32_t first = head ? obs_shift : 16u;
+            const uint32_t count = head ? ((16u - obs_shift) & 15u) : ((uint32_t)end & 15u);
+            if ((uint32_t)lane - first < count) g_al[byte] = img[byte];
         } else if (K == 1) {
             // ---- 7. the persistent tape kernel's copy-out (and, until round 3, every launch's): LDS image -> HBM, 16 bytes
             //         per lane, 1 KiB contiguous per wave instruction.  The 3969-byte images are not 16-byte multiples,
@@ -1503,7 +1550,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         if (PCACHE && !short_rec && MODE != 3) {
             const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO);
             bool late;
-            if (refilled)  // Philox already ran (ahead of some logic): again only if what it left cannot fill the parking words
+            if (refilled != 0)  // Philox already ran (ahead of some logic): again only if what it left cannot fill the parking words
                 late = !(draws_n == 64 && ctr_lo - draw_base + HDR_PC_N <= 64u);
             else if (MSNAKE_LATE_REFILL == 0)
                 late = rdlane(hv, HDR_PC_VALID) != 1u || ctr_lo - rdlane(hv, HDR_PC_BASE) > HDR_PC_N - 5u * NS;  // (mod 2^32, like ensure_draws)
@@ -1515,9 +1562,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             }
         }
 #endif
-        if (PCACHE && refilled && !short_rec) {
+        if (PCACHE && uni(refilled) == 1u) {
             // Philox ran in this launch: its unused draws go into the record for the launches to come
-            if (UPPER_TRACKED) upper_dirty = true;
+            upper_is_dirty();
             const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO);
             const uint32_t off = ctr_lo - draw_base;
             if (draws_n == 64 && off + HDR_PC_N <= 64u) {
@@ -1529,7 +1576,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 HV_SET_C(HDR_PC_VALID, 0u);
             }
         }
-        if ((lane < MSNAKE_HDR_SHORT_WORDS || (!short_rec && upper_dirty))) {
+        // (the number of words as ONE scalar select and one lane compare, not an or of lane masks)
+        const uint32_t rec_words = uni((uint32_t)MSNAKE_HDR_SHORT_WORDS + rec_extra);
+        if ((uint32_t)lane < rec_words) {
             uint32_t ee = (uint32_t)e;
             if (MODE == 3) asm volatile("" : "+s"(ee));  // (the pointer is not held across the step loop)
             // (round 3: the nt hint on this store, on the ring-sector stores and on the reward store -- nothing left dirty in the
