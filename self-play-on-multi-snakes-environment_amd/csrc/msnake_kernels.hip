@@ -1143,6 +1143,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         //         s's head.  [S] only needs "any j" per s; [N] needs the full matrix -------------
         uint32_t hitl = 0;      // [N]: per-lane accumulation, bit (4*s + j)
         uint64_t hit_s[NS];     // [S]/[A]: lanes whose cell lies on snake s's head (own head slot excluded)
+        uint32_t crvv[NS], crvo[NS];  // [S]/[A]: this lane's cell of snake j, ~0 where the slot holds no piece (crvo: nor in the head's slot)
 #pragma unroll
         for (int s = 0; s < NS; ++s) hit_s[s] = 0;
 #pragma unroll
@@ -1155,14 +1156,33 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
                 for (int s = 0; s < NS; ++s)
                     hitl |= (valid && cr[j] == hd[s] && !(j == s && pi == 0)) ? (1u << (4 * s + j)) : 0u;
             } else {
-                // slots that hold no piece compare as "no cell": one select per snake instead of a mask AND per pair
-                const uint32_t crv = valid ? cr[j] : 0xFFFFFFFFu;
+                // slots that hold no piece compare as "no cell", and so does a snake's own head slot against its own head
+                crvv[j] = valid ? cr[j] : 0xFFFFFFFFu;
+                crvo[j] = pi == 0 ? 0xFFFFFFFFu : crvv[j];
+                if (RULES == MSNAKE_RULES_ADVERSARIAL) {
+                    // (the adversarial kernels keep the lane-mask form: the vector form below costs them 3 more spilled SGPRs)
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    uint64_t m = lanes_where<CMP_EQ>(crv, hd[s]);
-                    if (j == s) m &= ~(1ull << (wc[j] >> SN_C_HP0_SHIFT));
-                    hit_s[s] |= m;
+                    for (int s = 0; s < NS; ++s) {
+                        uint64_t m = lanes_where<CMP_EQ>(crvv[j], hd[s]);
+                        if (j == s) m &= ~(1ull << (wc[j] >> SN_C_HP0_SHIFT));
+                        hit_s[s] |= m;
+                    }
                 }
+            }
+        }
+        if (RULES == MSNAKE_RULES_SNAKE_ENV) {
+            // "some piece lies on snake s's head" per lane as ONE number: the minimum over the snakes of cell ^ head is 0 iff
+            // one of them matches -- vector xor / min and one compare per head, instead of a lane mask per (snake, head) pair
+            // and-ed and or-ed on the scalar unit (this kernel's busiest port: a scalar instruction costs a launch 7.5 ns here)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                uint32_t d = 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    const uint32_t x = (j == s ? crvo[j] : crvv[j]) ^ hd[s];
+                    d = x < d ? x : d;
+                }
+                hit_s[s] = lanes_where<CMP_EQ>(d, 0u);
             }
         }
         if (longbody) {  // bodies longer than one chunk: the rest comes from the ring
