@@ -21,10 +21,28 @@ def isa(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
     out = tmp_path_factory.mktemp("isa") / "k.s"
-    subprocess.run([HIPCC, "-Os", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-S",
-                    "--cuda-device-only", "-o", str(out), SRC], check=True, stderr=subprocess.DEVNULL)
+    r = subprocess.run([HIPCC, "-Os", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-S",
+                        "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", str(out), SRC], check=True,
+                       capture_output=True, text=True)
     text = out.read_text()
-    return re.split(r"\n(?=_ZN6msnake18msnake_step_kernel\w+:)", text)[1:]
+    funcs = re.split(r"\n(?=_ZN6msnake18msnake_step_kernel\w+:)", text)[1:]
+    # register use per kernel from the resource remarks: {mangled name: {"VGPRs": n, "SGPRs Spill": n, ...}}
+    res, cur = {}, None
+    for line in r.stderr.split("\n"):
+        m = re.search(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill): (\S+)", line)
+        if not m:
+            continue
+        k, v = m.groups()
+        if k == "Function Name":
+            cur = res.setdefault(v, {})
+        else:
+            cur[k] = int(v)
+    funcs_and_resources.resources = res
+    return funcs
+
+
+class funcs_and_resources:  # (the resource table of the module-scoped compile above)
+    resources = {}
 
 
 def _regs(tok):
@@ -59,3 +77,19 @@ def test_streaming_copy_out_emits_nt_stores(isa):
     nt = len(re.findall(r"global_store_dwordx4 .* nt\b", head))
     plain = len([l for l in re.findall(r"global_store_dwordx4 [^\n]*", head) if not l.rstrip().endswith("nt")])
     assert nt >= 4 and plain >= 4, (nt, plain)  # both store kinds of the aligned copy-out, four 1 KiB instructions each
+
+
+def test_snake_env_per_step_kernels_do_not_spill(isa):
+    """The headline instantiation stays within 48 VGPRs (the allocation granule it was tuned for) and no per-step, reset or render
+    kernel of snake_env spills a register or uses scratch (msnake_step_kernel<RULES = 0, NS, MODE in {0, 1, 2}, K>)."""
+    res = funcs_and_resources.resources
+    seen = 0
+    for name, r in res.items():
+        m = re.match(r"_ZN6msnake18msnake_step_kernelILi0ELi(\d)ELi([012])ELi(\d)E", name)
+        if not m:
+            continue
+        seen += 1
+        assert r["SGPRs Spill"] == 0 and r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, (name[:60], r)
+        if m.groups() == ("3", "0", "1"):
+            assert r["VGPRs"] <= 48, r
+    assert seen >= 27
