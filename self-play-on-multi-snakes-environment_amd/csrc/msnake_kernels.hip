@@ -441,7 +441,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     constexpr bool UPPER_TRACKED = RULES == MSNAKE_RULES_SNAKE_ENV;
     // words of the record beyond the first 32 that go back to memory at the end of the step (0 or 32; a number, see `refilled`)
     uint32_t rec_extra = (UPPER_TRACKED || short_rec) ? 0u : (uint32_t)(MSNAKE_HDR_WORDS - MSNAKE_HDR_SHORT_WORDS);
-    auto upper_is_dirty = [&]() { if (UPPER_TRACKED) rec_extra = short_rec ? 0u : (uint32_t)(MSNAKE_HDR_WORDS - MSNAKE_HDR_SHORT_WORDS); };
+    auto upper_is_dirty = [&]() { if (UPPER_TRACKED) rec_extra = (MODE != 3 && short_rec) ? 0u : (uint32_t)(MSNAKE_HDR_WORDS - MSNAKE_HDR_SHORT_WORDS); };
     auto refill_draws = [&](uint32_t ctr_lo, uint32_t ctr_hi) {
         uint32_t ee = (uint32_t)e;
         asm volatile("" : "+s"(ee));  // (slow path only, like the key schedule below)
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         else
 #endif
         draws = philox_draws(ctr_lo, ctr_hi, lane, (uint32_t)gid, (uint32_t)(gid >> 32), k0, k1);
-        draw_base = ctr_lo; draws_n = 64; refilled = short_rec ? 2u : 1u;
+        draw_base = ctr_lo; draws_n = 64; refilled = MODE == 3 ? 1u : (short_rec ? 2u : 1u);
         SPAN_FLAG(4u);
     };
     // the next `need` (<= 64) draws are cached afterwards.  Callers run this BEFORE they build
@@ -1582,7 +1582,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             }
         }
 #endif
-        if (PCACHE && uni(refilled) == 1u) {
+        if (PCACHE && (MODE == 3 ? (refilled != 0 && !short_rec) : uni(refilled) == 1u)) {
             // Philox ran in this launch: its unused draws go into the record for the launches to come
             upper_is_dirty();
             const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO);
@@ -1597,7 +1597,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             }
         }
         // (the number of words as ONE scalar select and one lane compare, not an or of lane masks)
-        const uint32_t rec_words = uni((uint32_t)MSNAKE_HDR_SHORT_WORDS + rec_extra);
+        const uint32_t rec_words = uni((uint32_t)MSNAKE_HDR_SHORT_WORDS + ((MODE == 3 && short_rec) ? 0u : rec_extra));
         if ((uint32_t)lane < rec_words) {
             uint32_t ee = (uint32_t)e;
             if (MODE == 3) asm volatile("" : "+s"(ee));  // (the pointer is not held across the step loop)

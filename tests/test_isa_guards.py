@@ -79,17 +79,17 @@ def test_streaming_copy_out_emits_nt_stores(isa):
     assert nt >= 4 and plain >= 4, (nt, plain)  # both store kinds of the aligned copy-out, four 1 KiB instructions each
 
 
-def test_snake_env_per_step_kernels_do_not_spill(isa):
-    """The headline instantiation stays within 48 VGPRs (the allocation granule it was tuned for) and no per-step, reset or render
-    kernel of snake_env spills a register or uses scratch (msnake_step_kernel<RULES = 0, NS, MODE in {0, 1, 2}, K>)."""
+def test_snake_env_kernels_do_not_spill(isa):
+    """The headline instantiation stays within 48 VGPRs (the allocation granule it was tuned for) and no snake_env kernel -- per-step,
+    reset, render or persistent tape -- spills a register or uses scratch (msnake_step_kernel<RULES = 0, NS, MODE, K>)."""
     res = funcs_and_resources.resources
     seen = 0
     for name, r in res.items():
-        m = re.match(r"_ZN6msnake18msnake_step_kernelILi0ELi(\d)ELi([012])ELi(\d)E", name)
+        m = re.match(r"_ZN6msnake18msnake_step_kernelILi0ELi(\d)ELi([0123])ELi(\d)E", name)
         if not m:
             continue
         seen += 1
         assert r["SGPRs Spill"] == 0 and r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, (name[:60], r)
         if m.groups() == ("3", "0", "1"):
             assert r["VGPRs"] <= 48, r
-    assert seen >= 27
+    assert seen >= 36
