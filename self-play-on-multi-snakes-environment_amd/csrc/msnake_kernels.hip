@@ -432,6 +432,9 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // short record (nowhere to park).  (Wave-uniform flags are kept as NUMBERS: as bools they become 64-bit lane masks, and
     // every test of a combination of them is a handful of scalar instructions on this kernel's busiest port.)
     uint32_t refilled = 0;
+    // (the tape kernels and the adversarial ones keep the short-record test at the END of the step instead: folding it into the
+    //  flags keeps the test alive across their slow paths, which costs them SGPRs they do not have)
+    constexpr bool NUMFLAGS = MODE != 3 && RULES != MSNAKE_RULES_ADVERSARIAL;
 #ifdef MSNAKE_LATE_REFILL
     uint32_t slow_step = 0;  // != 0: this wave respawned a fruit or ended an episode in this launch (MODE 0 / 1)
 #endif
@@ -440,8 +443,8 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
     // there; the adversarial kernels have no SGPR to spare for the flag.)
     constexpr bool UPPER_TRACKED = RULES == MSNAKE_RULES_SNAKE_ENV;
     // words of the record beyond the first 32 that go back to memory at the end of the step (0 or 32; a number, see `refilled`)
-    uint32_t rec_extra = (UPPER_TRACKED || short_rec) ? 0u : (uint32_t)(MSNAKE_HDR_WORDS - MSNAKE_HDR_SHORT_WORDS);
-    auto upper_is_dirty = [&]() { if (UPPER_TRACKED) rec_extra = (MODE != 3 && short_rec) ? 0u : (uint32_t)(MSNAKE_HDR_WORDS - MSNAKE_HDR_SHORT_WORDS); };
+    uint32_t rec_extra = (UPPER_TRACKED || (NUMFLAGS && short_rec)) ? 0u : (uint32_t)(MSNAKE_HDR_WORDS - MSNAKE_HDR_SHORT_WORDS);
+    auto upper_is_dirty = [&]() { if (UPPER_TRACKED) rec_extra = (NUMFLAGS && short_rec) ? 0u : (uint32_t)(MSNAKE_HDR_WORDS - MSNAKE_HDR_SHORT_WORDS); };
     auto refill_draws = [&](uint32_t ctr_lo, uint32_t ctr_hi) {
         uint32_t ee = (uint32_t)e;
         asm volatile("" : "+s"(ee));  // (slow path only, like the key schedule below)
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
         else
 #endif
         draws = philox_draws(ctr_lo, ctr_hi, lane, (uint32_t)gid, (uint32_t)(gid >> 32), k0, k1);
-        draw_base = ctr_lo; draws_n = 64; refilled = MODE == 3 ? 1u : (short_rec ? 2u : 1u);
+        draw_base = ctr_lo; draws_n = 64; refilled = !NUMFLAGS ? 1u : (short_rec ? 2u : 1u);
         SPAN_FLAG(4u);
     };
     // the next `need` (<= 64) draws are cached afterwards.  Callers run this BEFORE they build
@@ -1582,7 +1585,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             }
         }
 #endif
-        if (PCACHE && (MODE == 3 ? (refilled != 0 && !short_rec) : uni(refilled) == 1u)) {
+        if (PCACHE && (!NUMFLAGS ? (refilled != 0 && !short_rec) : uni(refilled) == 1u)) {
             // Philox ran in this launch: its unused draws go into the record for the launches to come
             upper_is_dirty();
             const uint32_t ctr_lo = rdlane(hv, HDR_CTR_LO);
@@ -1597,7 +1600,7 @@ __global__ __launch_bounds__(MSNAKE_BLOCK_THREADS) void msnake_step_kernel(
             }
         }
         // (the number of words as ONE scalar select and one lane compare, not an or of lane masks)
-        const uint32_t rec_words = uni((uint32_t)MSNAKE_HDR_SHORT_WORDS + ((MODE == 3 && short_rec) ? 0u : rec_extra));
+        const uint32_t rec_words = uni((uint32_t)MSNAKE_HDR_SHORT_WORDS + ((!NUMFLAGS && short_rec) ? 0u : rec_extra));
         if ((uint32_t)lane < rec_words) {
             uint32_t ee = (uint32_t)e;
             if (MODE == 3) asm volatile("" : "+s"(ee));  // (the pointer is not held across the step loop)
